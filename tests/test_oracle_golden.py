@@ -1,0 +1,83 @@
+"""Pins oracle/cheb_oracle.py against the golden vectors produced by running the reference
+(tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, golden_ids, load_golden, rel_err
+from oracle import cheb_oracle as O
+
+TOL = 1e-5   # max|a-b|/max|b| <= 1e-5, fp32
+
+
+def _L(g):
+    return O.csr_from_arrays(g["n"], g["rowptr"], g["col"], g["val"])
+
+
+def _bias(g):
+    return g["bias"] if int(g["has_bias"]) else None
+
+
+@pytest.mark.parametrize("path", golden_files("GCNCheb_"), ids=golden_ids(golden_files("GCNCheb_")))
+def test_gcncheb(path):
+    g = load_golden(path)
+    out = O.gcn_cheb_forward(_L(g), g["x"], g["weight"], _bias(g))
+    assert rel_err(out, g["out"]) <= TOL
+    if g["stack"].size:
+        x = g["x"][:, :, None] if g["x"].ndim == 2 else g["x"]
+        assert rel_err(O.stack_reference_power(_L(g), x, int(g["K"])), g["stack"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("TGCNCheb_"), ids=golden_ids(golden_files("TGCNCheb_")))
+def test_tgcncheb(path):
+    g = load_golden(path)
+    assert rel_err(O.tgcn_cheb_forward(_L(g), g["x"], g["weight"], _bias(g)), g["out"]) <= TOL
+    assert rel_err(O.stack_reference_power(_L(g), g["x"], int(g["K"])), g["stack"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("TGCNChebH_"), ids=golden_ids(golden_files("TGCNChebH_")))
+def test_tgcncheb_h(path):
+    g = load_golden(path)
+    assert rel_err(O.tgcn_cheb_h_forward(_L(g), g["x"], g["weight"], _bias(g)), g["out"]) <= TOL
+    if g["stack"].size:
+        x = g["x"][..., None] if g["x"].ndim == 3 else g["x"]
+        assert rel_err(O.stack_reference_power(_L(g), x, int(g["K"])), g["stack"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("ChebConv_"), ids=golden_ids(golden_files("ChebConv_")))
+def test_chebconv(path):
+    g = load_golden(path)
+    w = g["edge_weight"] if int(g["use_weight"]) else None
+    assert rel_err(O.cheb_conv_forward(g["x"], g["edge_index"], w, g["weight"], _bias(g)), g["out"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("ChebTimeConv_"), ids=golden_ids(golden_files("ChebTimeConv_")))
+def test_chebtimeconv(path):
+    g = load_golden(path)
+    w = g["edge_weight"] if int(g["use_weight"]) else None
+    assert rel_err(O.cheb_time_conv_forward(g["x"], g["edge_index"], w, g["weight"], _bias(g)), g["out"]) <= TOL
+
+
+def test_spmm_helpers():
+    g = load_golden(golden_files("spmm_")[0])
+    n = int(g["n"])
+    assert rel_err(O.spmm(g["edge_index"], g["value"], n, g["m1"]), g["out1"]) <= TOL
+    assert rel_err(O.spmm(g["edge_index"], g["value"], n, g["v1"]), g["outv1"]) <= TOL
+    assert rel_err(O.spmm_batch(g["edge_index"], g["value"], n, g["m2"]), g["out2"]) <= TOL
+    assert rel_err(O.spmm_batch(g["edge_index"], g["value"], n, g["m3"]), g["out3"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("graph_chebyshev"), ids=golden_ids(golden_files("graph_chebyshev")))
+def test_graph_chebyshev(path):
+    g = load_golden(path)
+    L = _L(g).astype(g["val"].dtype)
+    out = O.graph_chebyshev(L, g["X"], int(g["K"]))
+    assert out.dtype == g["out"].dtype
+    # same scipy CSR kernels in the same order: bit-exact
+    assert np.array_equal(out, g["out"])
+
+
+def test_uniform_and_pool():
+    g = load_golden(golden_files("uniform_pool")[0])
+    assert np.abs(g["uniform_out"]).max() <= O.uniform_bound(int(g["uniform_size"]))
+    assert np.array_equal(O.gcn_pool(g["pool_x"], 2), g["pool2"])
+    assert np.array_equal(O.gcn_pool(g["pool_x"], 4), g["pool4"])
