@@ -1,0 +1,131 @@
+/* tgcn_hip.h -- C ABI of libtgcn_hip.so: the Chebyshev (time-)graph convolution hot path of
+ * cassianobecker/tgcn as hand-written HIP for gfx950 (MI355X).
+ *
+ * The reference has no native layer: its "operator API" for this path is the Python class surface of
+ * tgcn/nn/gcn.py (TGCNCheb :8, TGCNCheb_H :82, GCNCheb :158, ChebConv :348, ChebTimeConv :445) and
+ * gcn/graph.py::chebyshev (:241).  The entry points below are what a maintainer of the reference would
+ * bind (ctypes) to replace the stock-torch ops inside those forwards; every entry
+ * point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller; fp32, row-major, last dim contiguous
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); NULL = default
+ *   - nothing allocates, frees or synchronises; scratch comes from the caller (see *_workspace_bytes)
+ *   - returns 0 on success, a negative TGCN_ERR_* code otherwise; tgcn_last_error() gives the text
+ *     (thread-local).  Nothing throws across the ABI.  Launches go to the calling thread's current device.
+ */
+#ifndef TGCN_HIP_H
+#define TGCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGCN_OK 0
+#define TGCN_ERR_INVALID (-1)     /* bad argument (shape, alignment, null pointer) */
+#define TGCN_ERR_LAUNCH (-2)      /* HIP launch error */
+#define TGCN_ERR_WORKSPACE (-3)   /* caller workspace too small */
+#define TGCN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
+
+#define TGCN_ABI_VERSION 1
+
+/* One stored entry of the sparse operand: 8 bytes, read with a single load. */
+typedef struct tgcn_edge {
+  int32_t col;
+  float val;
+} tgcn_edge;
+
+/* CSR operand L-hat (n x n).  Replaces the dense (n,n) `self.L` of gcn.py:18,92,168 and the per-call
+ * (edge_index, lap) pair of gcn.py:413,510. */
+typedef struct tgcn_csr {
+  int64_t n;
+  int64_t nnz;           /* < 2^31 */
+  const int32_t* rowptr; /* [n+1] */
+  const tgcn_edge* edges; /* [nnz], rows in order */
+} tgcn_csr;
+
+/* nnz-balanced row-block schedule (built once per operand and lane-group width by the host side).
+ * Rows with more than `long_thresh` stored entries are cut into segments of at most `long_thresh`
+ * entries which are summed to scratch and folded by a fix-up launch (deterministic order). */
+typedef struct tgcn_csr_sched {
+  int32_t lanes_per_row; /* lane-group width the schedule was balanced for: 1,2,4,...,64 */
+  int32_t long_thresh;
+  int32_t nblk;  /* row blocks (one workgroup each) */
+  int32_t nseg;  /* long-row segments */
+  int32_t nlong; /* long rows */
+  int32_t reserved;
+  const int32_t* blk_row;  /* [nblk+1] first row of each block; blk_row[nblk] == n */
+  const int32_t* seg_row;  /* [nseg] */
+  const int32_t* seg_e0;   /* [nseg] first entry */
+  const int32_t* seg_e1;   /* [nseg] one past last entry */
+  const int32_t* long_row; /* [nlong] */
+  const int32_t* long_seg; /* [nlong+1] first segment of each long row */
+} tgcn_csr_sched;
+
+/* Batched dense operand: element (b, i, c) lives at ptr[b*batch_stride + i*row_stride + c]. */
+typedef struct tgcn_dense {
+  float* ptr;
+  int64_t batch_stride;
+  int64_t row_stride;
+} tgcn_dense;
+
+const char* tgcn_last_error(void);
+int tgcn_abi_version(void);
+
+/* Geometry the host needs to build a schedule / size scratch for a row length C (floats).
+ * `aligned16` != 0 when every operand base, row stride and batch stride is a multiple of 4 floats. */
+int tgcn_hop_vec_width(int32_t C, int aligned16);      /* floats per lane: 4 or 1 */
+int tgcn_hop_lanes_per_row(int32_t C, int aligned16);  /* 1,2,...,64 */
+int tgcn_hop_groups_per_block(int32_t C, int aligned16); /* 256 / lanes_per_row */
+size_t tgcn_csr_hop_workspace_bytes(const tgcn_csr_sched* sched, int32_t nb, int32_t C, int aligned16);
+
+/* One hop of the recursion:  S = L-hat . X ;  P = S (optional) ;  Y = alpha*S + beta*Z (Z optional).
+ *   reference_power (gcn.py:72-78,147-153,230-236):  P_k = L P_{k-1};  Xt[k] = 2 P_k - Xt[k-2]
+ *   chebyshev       (gcn.py:423-431,521-527):        Tx_k = 2 L Tx_{k-1} - Tx_{k-2}
+ *   plain SpMM      (gcn.py:258-345 spmm*):          alpha=1, Z=NULL
+ * nb batches of (n x C) rows share the CSR. */
+int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t nb, int32_t C,
+                     const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Y,
+                     const tgcn_dense* P, void* workspace, size_t workspace_bytes);
+
+/* Stacked-hop dense projection (gcn.py:39,113,194 einsum; :420-431 / :519-527 per-hop matmul):
+ *   out[r(m), :] (+)= sum_t A_t[m, 0:Kc] . W[t*Kc:(t+1)*Kc, 0:N] + bias
+ * A_t: M x Kc with row stride lda[t]; W: (nterms*Kc) x N contiguous; fp32 MFMA, fp32 accumulate.
+ * Row map r(m) = (m % interleave) * n_vertices + m / interleave   (interleave = 1: identity).
+ * bias_kind: 0 none | 1 per channel [N] | 2 per vertex and channel [n_vertices*N] (vertex = r % n_vertices).
+ * `a` and `lda` are HOST arrays of length nterms (<= 32). */
+int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
+                          const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
+                          int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo);
+
+/* (Q, n, C) -> (n, Q, C) re-layout so that short per-sample rows become one long row per vertex. */
+int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int64_t Q, int64_t n, int32_t C);
+
+/* Whole layer forward: K-1 hops + projection, enqueued on `stream` (capturable in a hipGraph).
+ *   mode 0 "reference_power": W must be the monomial-folded weight (see tgcn_amd/functional.py);
+ *          out = sum_j (L^j x) W_j + bias          (TGCNCheb / TGCNCheb_H / GCNCheb)
+ *   mode 1 "chebyshev": out = sum_k T_k(L) x W_k + bias   (ChebConv / ChebTimeConv)
+ * x: (q, n, C) contiguous, C = H*f; W: (K*C) x N; out: (q, n, N) contiguous.
+ * layout 0: hops run on the (q, n, C) layout as is; layout 1: x is first re-laid to (n, q*C).
+ * q_chunk: samples per pass (layout 0 only; 0 = all).  Workspace: tgcn_cheb_forward_workspace_bytes. */
+size_t tgcn_cheb_forward_workspace_bytes(const tgcn_csr_sched* sched, int32_t K, int64_t q, int64_t n, int32_t C,
+                                         int32_t layout, int64_t q_chunk);
+int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t mode, int32_t K,
+                          int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
+                          const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
+                          void* workspace, size_t workspace_bytes);
+
+/* gcn_pool / gcn_pool_4 (gcn.py:246-255): max over p consecutive vertices; idx (nullable) receives the
+ * arg-max offset 0..p-1 for the backward. */
+int tgcn_pool_max_f32(void* stream, const float* x, float* out, int32_t* idx, int64_t q, int64_t n, int32_t f,
+                      int32_t p);
+int tgcn_pool_max_bwd_f32(void* stream, const float* grad_out, const int32_t* idx, float* grad_in, int64_t q,
+                          int64_t n, int32_t f, int32_t p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGCN_HIP_H */

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path (through the C ABI of libtgcn_hip.so) against
+  (1) the golden vectors produced by running the reference, and
+  (2) the numpy oracle on seeded random inputs (ragged rows, hubs, isolated vertices, odd widths).
+Tolerance: max|a-b| / max|b| <= 1e-5 per output tensor, fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, golden_ids, load_golden, rel_err
+from oracle import cheb_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _load_params(layer, g):
+    with torch.no_grad():
+        layer.weight.copy_(_dev(g["weight"]))
+        if int(g["has_bias"]):
+            layer.bias.copy_(_dev(g["bias"]))
+    return layer.cuda()
+
+
+def _dense_L(g):
+    return torch.tensor(O.csr_from_arrays(g["n"], g["rowptr"], g["col"], g["val"]).toarray(), dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------ golden
+@pytest.mark.parametrize("path", golden_files("GCNCheb_"), ids=golden_ids(golden_files("GCNCheb_")))
+def test_gcncheb_golden(path, gpu_device):
+    import tgcn_amd
+    g = load_golden(path)
+    K, f, gg = g["weight"].shape
+    layer = _load_params(tgcn_amd.GCNCheb(_dense_L(g), f, gg, K, bias=bool(g["has_bias"])), g)
+    with torch.no_grad():
+        out = layer(_dev(g["x"]))
+        assert rel_err(out.cpu().numpy(), g["out"]) <= TOL
+        if g["stack"].size:
+            assert rel_err(layer._chebyshev(_dev(g["x"])).cpu().numpy(), g["stack"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("TGCNCheb_"), ids=golden_ids(golden_files("TGCNCheb_")))
+def test_tgcncheb_golden(path, gpu_device):
+    import tgcn_amd
+    g = load_golden(path)
+    K, f, gg = g["weight"].shape
+    layer = _load_params(tgcn_amd.TGCNCheb(_dense_L(g), f, gg, K, bias=bool(g["has_bias"])), g)
+    with torch.no_grad():
+        assert rel_err(layer(_dev(g["x"])).cpu().numpy(), g["out"]) <= TOL
+        assert rel_err(layer._time_chebyshev(_dev(g["x"])).cpu().numpy(), g["stack"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("TGCNChebH_"), ids=golden_ids(golden_files("TGCNChebH_")))
+def test_tgcncheb_h_golden(path, gpu_device):
+    import tgcn_amd
+    g = load_golden(path)
+    K, H, f, gg = g["weight"].shape
+    layer = _load_params(tgcn_amd.TGCNCheb_H(_dense_L(g), f, gg, K, H, bias=bool(g["has_bias"])), g)
+    with torch.no_grad():
+        assert rel_err(layer(_dev(g["x"])).cpu().numpy(), g["out"]) <= TOL
+        if g["stack"].size:
+            assert rel_err(layer._time_chebyshev(_dev(g["x"])).cpu().numpy(), g["stack"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("ChebConv_"), ids=golden_ids(golden_files("ChebConv_")))
+def test_chebconv_golden(path, gpu_device):
+    import tgcn_amd
+    g = load_golden(path)
+    K, f, gg = g["weight"].shape
+    layer = _load_params(tgcn_amd.ChebConv(f, gg, K, bias=bool(g["has_bias"])), g)
+    w = _dev(g["edge_weight"]) if int(g["use_weight"]) else None
+    with torch.no_grad():
+        out = layer(_dev(g["x"]), _dev(g["edge_index"]), w)
+    assert rel_err(out.cpu().numpy(), g["out"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("ChebTimeConv_"), ids=golden_ids(golden_files("ChebTimeConv_")))
+def test_chebtimeconv_golden(path, gpu_device):
+    import tgcn_amd
+    g = load_golden(path)
+    K, H, f, gg = g["weight"].shape
+    layer = _load_params(tgcn_amd.ChebTimeConv(f, gg, K, H, bias=bool(g["has_bias"])), g)
+    w = _dev(g["edge_weight"]) if int(g["use_weight"]) else None
+    with torch.no_grad():
+        out = layer(_dev(g["x"]), _dev(g["edge_index"]), w)
+    assert rel_err(out.cpu().numpy(), g["out"]) <= TOL
+
+
+def test_spmm_helpers_golden(gpu_device):
+    import tgcn_amd
+    g = load_golden(golden_files("spmm_")[0])
+    n = int(g["n"])
+    ei, v = _dev(g["edge_index"]), _dev(g["value"])
+    assert rel_err(tgcn_amd.spmm(ei, v, n, _dev(g["m1"])).cpu().numpy(), g["out1"]) <= TOL
+    assert rel_err(tgcn_amd.spmm(ei, v, n, _dev(g["v1"])).cpu().numpy(), g["outv1"]) <= TOL
+    assert rel_err(tgcn_amd.spmm_batch_2(ei, v, n, _dev(g["m2"])).cpu().numpy(), g["out2"]) <= TOL
+    assert rel_err(tgcn_amd.spmm_batch_3(ei, v, n, _dev(g["m3"])).cpu().numpy(), g["out3"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("graph_chebyshev"), ids=golden_ids(golden_files("graph_chebyshev")))
+def test_graph_chebyshev_golden(path, gpu_device):
+    from tgcn_amd.numpy_api import chebyshev
+    g = load_golden(path)
+    L = O.csr_from_arrays(g["n"], g["rowptr"], g["col"], g["val"]).astype(g["val"].dtype)
+    out = chebyshev(L, g["X"], int(g["K"]))
+    assert out.dtype == g["out"].dtype and out.shape == g["out"].shape
+    assert rel_err(out, g["out"]) <= TOL
+
+
+def test_pool_golden(gpu_device):
+    import tgcn_amd
+    g = load_golden(golden_files("uniform_pool")[0])
+    x = _dev(g["pool_x"])
+    assert np.array_equal(tgcn_amd.gcn_pool(x).cpu().numpy(), g["pool2"])
+    assert np.array_equal(tgcn_amd.gcn_pool_4(x).cpu().numpy(), g["pool4"])
+    xg = x.clone().requires_grad_(True)
+    tgcn_amd.gcn_pool_4(xg).sum().backward()
+    ref = x.clone().requires_grad_(True)
+    ref.reshape(3, 4, 4, 5).max(dim=2)[0].sum().backward()
+    assert torch.equal(xg.grad, ref.grad)
+
+
+# ------------------------------------------------------------------------------------------ oracle, random inputs
+def _random_graph(n, avg_deg, rng, hubs=(), isolated=()):
+    m = n * avg_deg
+    row = rng.integers(0, n, m)
+    col = rng.integers(0, n, m)
+    for h, d in hubs:                      # long rows -> segment path
+        row = np.concatenate([row, np.full(d, h)])
+        col = np.concatenate([col, rng.integers(0, n, d)])
+    keep = ~np.isin(row, list(isolated))
+    row, col = row[keep], col[keep]
+    val = rng.standard_normal(row.shape[0]).astype(np.float32) / np.sqrt(avg_deg)
+    return row, col, val
+
+
+@pytest.mark.parametrize("nb,n,C", [(1, 300, 1), (3, 300, 3), (2, 257, 4), (2, 500, 28), (1, 1000, 64), (3, 200, 100),
+                                    (1, 150, 300), (1, 90, 1200), (2, 64, 260), (5, 33, 7), (1, 2000, 16), (2, 700, 32)])
+def test_hop_vs_oracle(nb, n, C, gpu_device):
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(n * 1000 + C)
+    row, col, val = _random_graph(n, 9, rng, hubs=((5, 700), (n - 1, 1300)), isolated=(0, 7, n // 2))
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((nb, n, C)).astype(np.float32)
+    z = rng.standard_normal((nb, n, C)).astype(np.float32)
+    s = O._apply(L, x)
+    y = F.csr_hop(op, _dev(x))
+    assert rel_err(y.cpu().numpy(), s) <= TOL
+    y, p = F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0, want_p=True)
+    assert rel_err(p.cpu().numpy(), s) <= TOL
+    assert rel_err(y.cpu().numpy(), 2 * s - z) <= TOL
+    # isolated vertices: rows of zeros in L  =>  exactly beta*z
+    assert np.array_equal(y.cpu().numpy()[:, 7], -z[:, 7])
+    # run-to-run determinism (fixed summation order, no atomics)
+    y2 = F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0)
+    assert torch.equal(y, y2)
+
+
+def test_hop_linearity_large(gpu_device):
+    """Size-independent property at a size the oracle would not finish quickly: L(a x1 + x2) = a L x1 + L x2."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, m, C = 400_000, 6_000_000, 64
+    row = torch.randint(0, n, (m,), device="cuda", generator=g)
+    col = (torch.rand(m, device="cuda", generator=g) ** 3 * n).long().clamp_(max=n - 1)   # skewed: hubs
+    val = torch.randn(m, device="cuda", generator=g) * 0.1
+    op = GraphOperand.from_coo(n, row, col, val)
+    opT = op.transpose()
+    x1 = torch.randn(1, n, C, device="cuda", generator=g)
+    x2 = torch.randn(1, n, C, device="cuda", generator=g)
+    lhs = F.csr_hop(op, 0.5 * x1 + x2)
+    rhs = 0.5 * F.csr_hop(op, x1) + F.csr_hop(op, x2)
+    assert rel_err(lhs.cpu().numpy(), rhs.cpu().numpy()) <= TOL
+    # adjoint identity <L x1, x2> = <x1, L^T x2> (exercises the long-row path of the transposed operand)
+    a = (F.csr_hop(op, x1).double() * x2.double()).sum()
+    b = (x1.double() * F.csr_hop(opT, x2).double()).sum()
+    assert abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1.0)
+
+
+@pytest.mark.parametrize("M,Kc,N,T,inter", [(100, 1, 8, 5, 1), (1000, 28, 64, 5, 1), (777, 64, 64, 3, 1), (640, 15, 32, 10, 1),
+                                            (333, 7, 5, 2, 1), (1200, 12, 15, 4, 4), (64 * 9, 3, 100, 2, 9), (500, 36, 40, 33, 1)])
+def test_project_vs_numpy(M, Kc, N, T, inter, gpu_device):
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(M + Kc)
+    terms = [rng.standard_normal((M, Kc)).astype(np.float32) for _ in range(T)]
+    W = (rng.standard_normal((T, Kc, N)) / np.sqrt(T * Kc)).astype(np.float32)
+    nv = M // inter
+    for kind, bias in ((0, None), (1, rng.standard_normal(N).astype(np.float32)),
+                       (2, rng.standard_normal((nv, N)).astype(np.float32))):
+        ref = sum(t.astype(np.float64) @ w.astype(np.float64) for t, w in zip(terms, W))
+        if inter > 1:      # m = i*inter + q  ->  row q*nv + i
+            ref = ref.reshape(nv, inter, N).transpose(1, 0, 2).reshape(M, N)
+        if kind == 1:
+            ref = ref + bias
+        elif kind == 2:
+            ref = (ref.reshape(-1, nv, N) + bias).reshape(M, N)
+        out = F.cheb_project([_dev(t) for t in terms], _dev(W), None if bias is None else _dev(bias), kind, nv, inter)
+        assert rel_err(out.cpu().numpy(), ref) <= TOL
+
+
+def test_relayout(gpu_device):
+    import ctypes as C
+    from tgcn_amd import _lib
+    for Q, n, c in ((5, 37, 1), (16, 16, 4), (33, 100, 15), (2, 1000, 31), (130, 50, 7)):
+        x = torch.randn(Q, n, c, device="cuda")
+        out = torch.empty(n, Q, c, device="cuda")
+        _lib.check(_lib.lib().tgcn_relayout_qnc_to_nqc_f32(_lib.stream_ptr(), _lib.ptr(x), _lib.ptr(out), Q, n, c))
+        assert torch.equal(out, x.permute(1, 0, 2).contiguous())
+
+
+@pytest.mark.parametrize("layout,q_chunk", [(0, 0), (0, 1), (0, 2), (1, 0)])
+def test_forward_layouts_agree(layout, q_chunk, gpu_device):
+    """The layer result must not depend on the internal layout / pass size."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(3)
+    n, q, Crow, N, K = 500, 5, 12, 24, 6
+    row, col, val = _random_graph(n, 8, rng, hubs=((3, 600),))
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((q, n, Crow)).astype(np.float32)
+    W = (rng.standard_normal((K, Crow, N)) / np.sqrt(K * Crow)).astype(np.float32)
+    b = rng.standard_normal((n, N)).astype(np.float32)
+    for mode, stack in ((F.MODE_CHEBYSHEV, O.stack_chebyshev), (F.MODE_POWER, None)):
+        if stack is None:    # mode 0 takes the monomial-folded weight: basis is L^j x
+            P = [x]
+            for _ in range(1, K):
+                P.append(O._apply(L, P[-1]))
+            basis = np.stack(P)
+        else:
+            basis = stack(L, x, K)
+        ref = np.einsum("kqnc,kcg->qng", basis.astype(np.float64), W.astype(np.float64)) + b
+        out = F.cheb_forward_raw(op, _dev(x), _dev(W.reshape(K * Crow, N)), _dev(b), 2, mode, K, layout=layout, q_chunk=q_chunk)
+        assert rel_err(out.cpu().numpy(), ref) <= TOL
+
+
+# ------------------------------------------------------------------------------------------ backward
+@pytest.mark.parametrize("cls", ["GCNCheb", "TGCNCheb_H", "ChebConv", "ChebTimeConv"])
+def test_backward_vs_dense_autograd(cls, gpu_device):
+    """Gradients of the HIP layer against torch autograd through a dense fp64 restatement of the same formula."""
+    import tgcn_amd
+    rng = np.random.default_rng(11)
+    n, q, K, H, f, g = 60, 3, 5, 4, 2, 6
+    row, col, val = _random_graph(n, 5, rng)
+    A = O.coo_to_csr(row, col, np.abs(val), n)
+    A = ((A + A.T) > 0).astype(np.float32)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    coo = A.tocoo()
+    ei = np.stack([coo.row, coo.col]).astype(np.int64)
+    r_, c_, lap = O.edge_laplacian(ei, None, n)
+    Ld = torch.tensor(O.coo_to_csr(r_, c_, lap, n).toarray(), dtype=torch.float64, device="cuda")
+    torch.manual_seed(0)
+    if cls == "GCNCheb":
+        layer = tgcn_amd.GCNCheb(Ld.float().cpu(), f, g, K).cuda()
+        x = torch.randn(q, n, f, device="cuda", requires_grad=True)
+        run = lambda: layer(x)
+    elif cls == "TGCNCheb_H":
+        layer = tgcn_amd.TGCNCheb_H(Ld.float().cpu(), f, g, K, H).cuda()
+        x = torch.randn(q, n, H, f, device="cuda", requires_grad=True)
+        run = lambda: layer(x)
+    elif cls == "ChebConv":
+        layer = tgcn_amd.ChebConv(f, g, K).cuda()
+        x = torch.randn(q, n, f, device="cuda", requires_grad=True)
+        run = lambda: layer(x, _dev(ei))
+    else:
+        layer = tgcn_amd.ChebTimeConv(f, g, K, H).cuda()
+        x = torch.randn(q, n, H, f, device="cuda", requires_grad=True)
+        run = lambda: layer(x, _dev(ei))
+    out = run()
+    go = torch.randn_like(out)
+    out.backward(go)
+    got = [x.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone()]
+
+    xd = x.detach().double().requires_grad_(True)
+    Wd = layer.weight.detach().double().requires_grad_(True)
+    bd = layer.bias.detach().double().requires_grad_(True)
+    x4 = xd.reshape(q, n, -1)
+    power = cls in ("GCNCheb", "TGCNCheb_H")
+    Xt = [x4]
+    P = x4
+    for k in range(1, K):
+        if power:
+            P = torch.einsum("nm,qmc->qnc", Ld, P)
+            Xt.append(P if k == 1 else 2 * P - Xt[k - 2])
+        else:
+            LX = torch.einsum("nm,qmc->qnc", Ld, Xt[k - 1])
+            Xt.append(LX if k == 1 else 2 * LX - Xt[k - 2])
+    ref = torch.einsum("kqnc,kcg->qng", torch.stack(Xt), Wd.reshape(K, -1, g)) + bd
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+    ref.backward(go.double())
+    for a, b in zip(got, (xd.grad, Wd.grad, bd.grad)):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy().reshape(a.shape)) <= 2e-5
+
+
+def test_cpu_tensor_fails_loudly():
+    import tgcn_amd
+    from tgcn_amd._lib import TgcnError
+    layer = tgcn_amd.GCNCheb(torch.eye(4), 1, 2, 2)
+    with pytest.raises(TgcnError):
+        layer(torch.randn(2, 4))

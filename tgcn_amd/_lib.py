@@ -1,0 +1,107 @@
+"""ctypes binding of libtgcn_hip.so (include/tgcn_hip.h).  There is no CPU fallback: if the shared
+library is missing or a tensor is not on a ROCm device the call fails loudly."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libtgcn_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", "tgcn_hip.hip")]
+INCLUDE = os.path.join(ROOT, "include")
+
+
+class TgcnError(RuntimeError):
+    pass
+
+
+class CsrStruct(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edges", C.c_void_p)]
+
+
+class SchedStruct(C.Structure):
+    _fields_ = [("lanes_per_row", C.c_int32), ("long_thresh", C.c_int32), ("nblk", C.c_int32), ("nseg", C.c_int32),
+                ("nlong", C.c_int32), ("reserved", C.c_int32), ("blk_row", C.c_void_p), ("seg_row", C.c_void_p),
+                ("seg_e0", C.c_void_p), ("seg_e1", C.c_void_p), ("long_row", C.c_void_p), ("long_seg", C.c_void_p)]
+
+
+class DenseStruct(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("batch_stride", C.c_int64), ("row_stride", C.c_int64)]
+
+
+# name -> (restype, argtypes); must list every symbol include/tgcn_hip.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "tgcn_last_error": (C.c_char_p, []),
+    "tgcn_abi_version": (C.c_int, []),
+    "tgcn_hop_vec_width": (C.c_int, [C.c_int32, C.c_int]),
+    "tgcn_hop_lanes_per_row": (C.c_int, [C.c_int32, C.c_int]),
+    "tgcn_hop_groups_per_block": (C.c_int, [C.c_int32, C.c_int]),
+    "tgcn_csr_hop_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int32, C.c_int]),
+    "tgcn_csr_hop_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
+                                   C.POINTER(DenseStruct), C.POINTER(DenseStruct), C.c_float, C.c_float,
+                                   C.POINTER(DenseStruct), C.POINTER(DenseStruct), _P, C.c_size_t]),
+    "tgcn_cheb_project_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P),
+                                        C.POINTER(C.c_int64), _P, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                                        _P, C.c_int64]),
+    "tgcn_relayout_qnc_to_nqc_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int32]),
+    "tgcn_cheb_forward_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64,
+                                                       C.c_int32, C.c_int32, C.c_int64]),
+    "tgcn_cheb_forward_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
+                                        C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P,
+                                        C.c_int32, C.c_int64, _P, C.c_size_t]),
+    "tgcn_pool_max_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_pool_max_bwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 into tgcn_amd/lib/libtgcn_hip.so (hipcc cross-compiles without a GPU)."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s)
+                                        for s in SOURCES + [os.path.join(INCLUDE, "tgcn_hip.h")]):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-I", INCLUDE, "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TgcnError("tgcn_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.tgcn_abi_version() != 1:
+            raise TgcnError("tgcn_amd: ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TgcnError("libtgcn_hip: %s (code %d)" % (lib().tgcn_last_error().decode(), rc))
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise TgcnError("tgcn_amd: the HIP path needs tensors on a ROCm device (got %s); there is no CPU fallback" % t.device)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,656 @@
+// tgcn_hip.hip -- gfx950 (MI355X) kernels + C ABI for the Chebyshev (time-)graph convolution.
+// See include/tgcn_hip.h for the contract and DESIGN.md for layout / roofline notes.
+//
+// Kernels
+//   hop_kernel<LPR,VEC>      row-block CSR x dense rows, fused  Y = alpha*(L X) + beta*Z  (+ P = L X)
+//   hop_fixup_kernel<..>     folds long-row segment partials (fixed order => deterministic)
+//   project_kernel<NT,VEC4>  stacked-hop projection on v_mfma_f32_16x16x4_f32 (exact fp32)
+//   relayout_kernel          (Q,n,C) -> (n,Q,C)
+//   pool_max_kernel / _bwd   gcn_pool / gcn_pool_4
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "tgcn_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+#define TGCN_FAIL(code, ...)                    \
+  do {                                          \
+    snprintf(g_err, sizeof(g_err), __VA_ARGS__); \
+    return (code);                              \
+  } while (0)
+
+#define TGCN_CHECK_LAUNCH(what)                                                         \
+  do {                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                  \
+    if (e_ != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr int kBlock = 256;
+
+// --------------------------------------------------------------------------------------------------
+// hop
+// --------------------------------------------------------------------------------------------------
+struct HopParams {
+  const int32_t* rowptr;
+  const tgcn_edge* ev;
+  const int32_t* blk_row;
+  const int32_t* seg_row;
+  const int32_t* seg_e0;
+  const int32_t* seg_e1;
+  const int32_t* long_row;
+  const int32_t* long_seg;
+  const float* X;
+  const float* Z;
+  float* Y;
+  float* P;
+  float* partial;
+  int64_t x_bs, x_ld, z_bs, z_ld, y_bs, y_ld, p_bs, p_ld;
+  float alpha, beta;
+  int32_t nblk, nseg, nlong, long_thresh;
+  int32_t C, nb, nchunks, cpad;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = __builtin_nontemporal_load(p);
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// XCD-aware block id: blocks b and b+8 share an XCD (observed round-robin dispatch), so hand each XCD a
+// contiguous range of row blocks -- neighbouring rows share neighbour columns in its private L2.
+// Bijective for every nblk (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// Sum of val_e * X[col_e, c0..c0+VEC) over stored entries [e0, e1), by one group of LPR lanes.
+// The group reads LPR entries with one coalesced 8-byte load per lane and hands them round with
+// in-register shuffles; gathers are issued U at a time so every lane keeps U 16-byte loads in flight.
+template <int LPR, int VEC>
+__device__ __forceinline__ void accum_range(const tgcn_edge* __restrict__ ev, int e0, int e1, int t,
+                                            const float* __restrict__ Xc, int64_t ldx, float (&acc)[VEC]) {
+  constexpr int U = LPR < 4 ? LPR : 4;
+  for (int eb = e0; eb < e1; eb += LPR) {
+    int my_c = 0;
+    float my_v = 0.f;
+    if (eb + t < e1) {
+      const tgcn_edge e = ev[eb + t];
+      my_c = e.col;
+      my_v = e.val;
+    }
+    const int cnt = min(LPR, e1 - eb);
+#pragma unroll
+    for (int j0 = 0; j0 < LPR; j0 += U) {
+      if (j0 >= cnt) break;
+      float xv[U][VEC];
+      float vv[U];
+      if (j0 + U <= cnt) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = __shfl(my_c, j0 + u, LPR);
+          vv[u] = __shfl(my_v, j0 + u, LPR);
+          load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
+        }
+      } else {  // ragged tail: clamp to the last valid entry, weight 0 (lanes past cnt hold val 0)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = min(j0 + u, cnt - 1);
+          const int c = __shfl(my_c, j, LPR);
+          vv[u] = (j0 + u < cnt) ? __shfl(my_v, j, LPR) : 0.f;
+          load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vv[u], xv[u][i], acc[i]);
+    }
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int c0, const float (&s)[VEC]) {
+  if (p.P) store_vec<VEC>(p.P + (int64_t)b * p.p_bs + (int64_t)r * p.p_ld + c0, s);
+  float y[VEC];
+  if (p.Z) {
+    float z[VEC];
+    load_vec_nt<VEC>(p.Z + (int64_t)b * p.z_bs + (int64_t)r * p.z_ld + c0, z);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = fmaf(p.alpha, s[i], p.beta * z[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = p.alpha * s[i];
+  }
+  if (p.Y) store_vec<VEC>(p.Y + (int64_t)b * p.y_bs + (int64_t)r * p.y_ld + c0, y);
+}
+
+template <int LPR, int VEC>
+__global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
+  constexpr int GPB = kBlock / LPR;
+  const int tid = threadIdx.x;
+  const int t = tid % LPR;
+  const int gib = tid / LPR;
+  const int chunk = blockIdx.y % p.nchunks;
+  const int b = blockIdx.y / p.nchunks;
+  const int c0 = (chunk * LPR + t) * VEC;
+  const bool cact = c0 < p.C;
+  const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
+  int bid = blockIdx.x;
+  if (bid < p.nblk) {
+    bid = xcd_remap(bid, p.nblk);
+    const int r0 = p.blk_row[bid], r1 = p.blk_row[bid + 1];
+    for (int r = r0 + gib; r < r1; r += GPB) {
+      const int e0 = p.rowptr[r], e1 = p.rowptr[r + 1];
+      if (e1 - e0 > p.long_thresh) continue;  // summed by segments below + hop_fixup_kernel
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      accum_range<LPR, VEC>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
+      if (cact) finish_row<VEC>(p, b, r, c0, acc);
+    }
+  } else {
+    const int s = (bid - p.nblk) * GPB + gib;
+    if (s < p.nseg) {
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      accum_range<LPR, VEC>(p.ev, p.seg_e0[s], p.seg_e1[s], t, Xc, p.x_ld, acc);
+      store_vec<VEC>(p.partial + ((int64_t)s * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc);
+    }
+  }
+}
+
+template <int LPR, int VEC>
+__global__ __launch_bounds__(kBlock) void hop_fixup_kernel(const HopParams p) {
+  constexpr int GPB = kBlock / LPR;
+  const int tid = threadIdx.x;
+  const int t = tid % LPR;
+  const int gib = tid / LPR;
+  const int chunk = blockIdx.y % p.nchunks;
+  const int b = blockIdx.y / p.nchunks;
+  const int c0 = (chunk * LPR + t) * VEC;
+  const int i = blockIdx.x * GPB + gib;
+  if (i >= p.nlong || c0 >= p.C) return;
+  const int row = p.long_row[i];
+  const int s0 = p.long_seg[i], s1 = p.long_seg[i + 1];
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  for (int s = s0; s < s1; ++s) {
+    float v[VEC];
+    load_vec<VEC>(p.partial + ((int64_t)s * p.nb + b) * p.cpad + c0, v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+  }
+  finish_row<VEC>(p, b, row, c0, acc);
+}
+
+struct HopGeom {
+  int vec, lpr, nchunks, cpad;
+};
+
+inline HopGeom hop_geom(int32_t C, int aligned16) {
+  HopGeom g;
+  g.vec = (aligned16 && (C % 4 == 0)) ? 4 : 1;
+  const int lanes = (C + g.vec - 1) / g.vec;
+  int lpr = 1;
+  while (lpr < lanes && lpr < 64) lpr <<= 1;
+  g.lpr = lpr;
+  g.nchunks = (lanes + lpr - 1) / lpr;
+  g.cpad = g.nchunks * lpr * g.vec;
+  return g;
+}
+
+template <int VEC>
+int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
+#define TGCN_HOP_CASE(L)                                                                   \
+  case L:                                                                                  \
+    hipLaunchKernelGGL((hop_kernel<L, VEC>), grid, dim3(kBlock), 0, st, p);                 \
+    if (p.nlong > 0) hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); \
+    break;
+  switch (lpr) {
+    TGCN_HOP_CASE(1)
+    TGCN_HOP_CASE(2)
+    TGCN_HOP_CASE(4)
+    TGCN_HOP_CASE(8)
+    TGCN_HOP_CASE(16)
+    TGCN_HOP_CASE(32)
+    TGCN_HOP_CASE(64)
+    default:
+      TGCN_FAIL(TGCN_ERR_INVALID, "hop: bad lanes_per_row %d", lpr);
+  }
+#undef TGCN_HOP_CASE
+  TGCN_CHECK_LAUNCH("tgcn_csr_hop_f32");
+  return TGCN_OK;
+}
+
+inline bool aligned4(const tgcn_dense* d) {
+  return d == nullptr || d->ptr == nullptr ||
+         (((uintptr_t)d->ptr & 15) == 0 && (d->batch_stride & 3) == 0 && (d->row_stride & 3) == 0);
+}
+
+// --------------------------------------------------------------------------------------------------
+// projection (fp32 MFMA)
+// --------------------------------------------------------------------------------------------------
+constexpr int kMaxTerms = 32;
+
+struct ProjParams {
+  const float* a[kMaxTerms];
+  int64_t lda[kMaxTerms];
+  const float* W;
+  const float* bias;
+  float* out;
+  int64_t M, ldo, n_vertices, interleave;
+  int32_t Kc, N, nterms, bias_kind, accumulate;
+};
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Block = 4 waves, 64 output rows; wave w owns rows [16w,16w+16) x NT*16 columns as NT accumulators of
+// v_mfma_f32_16x16x4_f32 (A[l&15][k=l>>4], B[k=l>>4][l&15], D col=l&15,row=(l>>4)*4+reg).
+// LDS strides: As 34 (== 2 mod 32) and Ws == 16 mod 32 make both fragment reads conflict-free.
+template <int NT, bool VEC4>
+__global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
+  constexpr int BM = 64, KT = 32, AS = KT + 2;
+  constexpr int NW = NT * 16;
+  constexpr int NS = (NW % 32 == 0) ? NW + 16 : NW;
+  __shared__ float As[BM * AS];
+  __shared__ float Ws[KT * NS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * NW;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int term = 0; term < p.nterms; ++term) {
+    const float* __restrict__ A = p.a[term];
+    const int64_t lda = p.lda[term];
+    const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
+    for (int k0 = 0; k0 < p.Kc; k0 += KT) {
+      // ---- global -> registers
+      float ra[8];
+      if constexpr (VEC4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m0 + row < p.M && k0 + kk < p.Kc)
+            v = *reinterpret_cast<const float4*>(A + (m0 + row) * lda + k0 + kk);
+          ra[h * 4 + 0] = v.x; ra[h * 4 + 1] = v.y; ra[h * 4 + 2] = v.z; ra[h * 4 + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          const int row = (tid >> 5) + h * 8, kk = tid & 31;
+          ra[h] = (m0 + row < p.M && k0 + kk < p.Kc) ? A[(m0 + row) * lda + k0 + kk] : 0.f;
+        }
+      }
+      float rw[(KT * NW + kBlock - 1) / kBlock];
+#pragma unroll
+      for (int h = 0; h < (KT * NW) / kBlock; ++h) {
+        const int idx = tid + h * kBlock;
+        const int kk = idx / NW, cc = idx % NW;
+        rw[h] = (k0 + kk < p.Kc && n0 + cc < p.N) ? Wt[(int64_t)(k0 + kk) * p.N + n0 + cc] : 0.f;
+      }
+      __syncthreads();  // everyone is done reading the previous tile
+      if constexpr (VEC4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
+          float2* d = reinterpret_cast<float2*>(&As[row * AS + kk]);
+          d[0] = make_float2(ra[h * 4 + 0], ra[h * 4 + 1]);
+          d[1] = make_float2(ra[h * 4 + 2], ra[h * 4 + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) As[((tid >> 5) + h * 8) * AS + (tid & 31)] = ra[h];
+      }
+#pragma unroll
+      for (int h = 0; h < (KT * NW) / kBlock; ++h) {
+        const int idx = tid + h * kBlock;
+        Ws[(idx / NW) * NS + (idx % NW)] = rw[h];
+      }
+      __syncthreads();
+      // ---- MFMA over the tile
+      const int kend = min(KT, p.Kc - k0);
+      const float* arow = &As[(wave * 16 + (lane & 15)) * AS + (lane >> 4)];
+      const float* brow = &Ws[(lane >> 4) * NS + (lane & 15)];
+#pragma unroll
+      for (int ks = 0; ks < KT / 4; ++ks) {
+        if (ks * 4 >= kend) break;
+        const float a = arow[ks * 4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float bv = brow[ks * 4 * NS + nt * 16];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- epilogue: bias, row map, store
+  const int col_l = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wave * 16 + (lane >> 4) * 4 + i;
+    if (m >= p.M) continue;
+    const int64_t r = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + nt * 16 + col_l;
+      if (col >= p.N) continue;
+      float v = acc[nt][i];
+      if (p.bias_kind == 1) v += p.bias[col];
+      else if (p.bias_kind == 2) v += p.bias[(r % p.n_vertices) * p.N + col];
+      float* o = p.out + r * p.ldo + col;
+      if (p.accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// relayout (Q,n,C) -> (n,Q,C), C <= 32
+// --------------------------------------------------------------------------------------------------
+constexpr int kRelT = 16;
+__global__ __launch_bounds__(kBlock) void relayout_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int64_t Q, int64_t n, int C) {
+  __shared__ float tile[kRelT * kRelT * 32];
+  const int64_t i0 = (int64_t)blockIdx.x * kRelT, q0 = (int64_t)blockIdx.y * kRelT;
+  const int seg = kRelT * C;  // floats per (q, 16 vertices) or per (vertex, 16 q)
+  for (int e = threadIdx.x; e < kRelT * seg; e += kBlock) {
+    const int q = e / seg, rem = e % seg;
+    float v = 0.f;
+    if (q0 + q < Q && i0 + rem / C < n) v = in[((q0 + q) * n + i0) * C + rem];
+    tile[e] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kRelT * seg; e += kBlock) {
+    const int i = e / seg, rem = e % seg;
+    const int q = rem / C, c = rem % C;
+    if (i0 + i < n && q0 + q < Q) out[((i0 + i) * Q + q0) * C + rem] = tile[(q * kRelT + i) * C + c];
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// pooling
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pool_max_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int32_t* __restrict__ idx, int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;  // (q, i_out) flattened
+    const int c = (int)(o % f);
+    const float* src = x + row * p * f + c;
+    float best = src[0];
+    int bi = 0;
+    for (int j = 1; j < p; ++j) {
+      const float v = src[(int64_t)j * f];
+      if (v > best || (v != v && best == best)) {  // NaN propagates like torch.max
+        best = v;
+        bi = j;
+      }
+    }
+    out[o] = best;
+    if (idx) idx[o] = bi;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pool_max_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx,
+                                                              float* __restrict__ gi, int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;
+    const int c = (int)(o % f);
+    const int bi = idx[o];
+    const float g = go[o];
+    float* dst = gi + row * p * f + c;
+    for (int j = 0; j < p; ++j) dst[(int64_t)j * f] = (j == bi) ? g : 0.f;
+  }
+}
+
+inline int grid_1d(int64_t total) {
+  int64_t g = (total + kBlock - 1) / kBlock;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+extern "C" {
+
+const char* tgcn_last_error(void) { return g_err; }
+int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
+
+int tgcn_hop_vec_width(int32_t C, int aligned16) { return C > 0 ? hop_geom(C, aligned16).vec : 0; }
+int tgcn_hop_lanes_per_row(int32_t C, int aligned16) { return C > 0 ? hop_geom(C, aligned16).lpr : 0; }
+int tgcn_hop_groups_per_block(int32_t C, int aligned16) { return C > 0 ? kBlock / hop_geom(C, aligned16).lpr : 0; }
+
+size_t tgcn_csr_hop_workspace_bytes(const tgcn_csr_sched* sched, int32_t nb, int32_t C, int aligned16) {
+  if (!sched || C <= 0 || nb <= 0) return 0;
+  return (size_t)sched->nseg * (size_t)nb * (size_t)hop_geom(C, aligned16).cpad * sizeof(float);
+}
+
+int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
+                     const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Y,
+                     const tgcn_dense* P, void* workspace, size_t workspace_bytes) {
+  if (!A || !S || !X || !X->ptr) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null operand");
+  if ((!Y || !Y->ptr) && (!P || !P->ptr)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: no output");
+  if (A->n <= 0 || A->nnz < 0 || A->nnz >= (int64_t)INT32_MAX || A->n >= (int64_t)INT32_MAX)
+    TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: n=%lld nnz=%lld outside int32 index range", (long long)A->n, (long long)A->nnz);
+  if (nb <= 0 || C <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: nb=%d C=%d", nb, C);
+  if (!A->rowptr || (A->nnz > 0 && !A->edges) || !S->blk_row) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null CSR/schedule array");
+  const int al = aligned4(X) && aligned4(Z) && aligned4(Y) && aligned4(P);
+  const HopGeom g = hop_geom(C, al);
+  if (S->lanes_per_row != g.lpr)
+    TGCN_FAIL(TGCN_ERR_INVALID, "hop: schedule built for %d lanes/row, C=%d (aligned16=%d) needs %d", S->lanes_per_row, C, al, g.lpr);
+  if (S->nblk <= 0 || S->long_thresh <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: empty schedule");
+  if ((int64_t)nb * g.nchunks > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: nb*chunks=%lld > 65535", (long long)nb * g.nchunks);
+  if (S->nseg > 0) {
+    const size_t need = (size_t)S->nseg * nb * g.cpad * sizeof(float);
+    if (!workspace || workspace_bytes < need) TGCN_FAIL(TGCN_ERR_WORKSPACE, "hop: workspace %zu < %zu", workspace_bytes, need);
+    if (!S->seg_row || !S->seg_e0 || !S->seg_e1 || !S->long_row || !S->long_seg) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null segment arrays");
+  }
+  HopParams p;
+  memset(&p, 0, sizeof(p));
+  p.rowptr = A->rowptr; p.ev = A->edges; p.blk_row = S->blk_row;
+  p.seg_row = S->seg_row; p.seg_e0 = S->seg_e0; p.seg_e1 = S->seg_e1; p.long_row = S->long_row; p.long_seg = S->long_seg;
+  p.X = X->ptr; p.x_bs = X->batch_stride; p.x_ld = X->row_stride;
+  if (Z && Z->ptr) { p.Z = Z->ptr; p.z_bs = Z->batch_stride; p.z_ld = Z->row_stride; }
+  if (Y && Y->ptr) { p.Y = Y->ptr; p.y_bs = Y->batch_stride; p.y_ld = Y->row_stride; }
+  if (P && P->ptr) { p.P = P->ptr; p.p_bs = P->batch_stride; p.p_ld = P->row_stride; }
+  p.partial = (float*)workspace;
+  p.alpha = alpha; p.beta = beta;
+  p.nblk = S->nblk; p.nseg = S->nseg; p.nlong = S->nlong; p.long_thresh = S->long_thresh;
+  p.C = C; p.nb = nb; p.nchunks = g.nchunks; p.cpad = g.cpad;
+  const int gpb = kBlock / g.lpr;
+  const int seg_blocks = (S->nseg + gpb - 1) / gpb;
+  const dim3 grid((unsigned)(S->nblk + seg_blocks), (unsigned)(nb * g.nchunks));
+  const dim3 fix_grid((unsigned)((S->nlong + gpb - 1) / gpb > 0 ? (S->nlong + gpb - 1) / gpb : 1), (unsigned)(nb * g.nchunks));
+  hipStream_t st = (hipStream_t)stream;
+  return g.vec == 4 ? launch_hop_vec<4>(st, p, g.lpr, grid, fix_grid) : launch_hop_vec<1>(st, p, g.lpr, grid, fix_grid);
+}
+
+int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
+                          const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
+                          int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo) {
+  if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "project: bad argument");
+  if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
+  if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "project: bias_kind %d", bias_kind);
+  if (interleave < 1 || n_vertices < 1) TGCN_FAIL(TGCN_ERR_INVALID, "project: interleave/n_vertices");
+  if (interleave > 1 && M != interleave * n_vertices) TGCN_FAIL(TGCN_ERR_INVALID, "project: M != interleave*n_vertices");
+  ProjParams p;
+  memset(&p, 0, sizeof(p));
+  bool vec4 = (Kc % 4 == 0);
+  for (int t = 0; t < nterms; ++t) {
+    if (!a[t]) TGCN_FAIL(TGCN_ERR_INVALID, "project: null term %d", t);
+    p.a[t] = a[t];
+    p.lda[t] = lda[t];
+    vec4 = vec4 && (((uintptr_t)a[t] & 15) == 0) && (lda[t] % 4 == 0);
+  }
+  p.W = W; p.bias = bias; p.out = out; p.M = M; p.ldo = ldo; p.n_vertices = n_vertices; p.interleave = interleave;
+  p.Kc = Kc; p.N = N; p.nterms = nterms; p.bias_kind = bias_kind; p.accumulate = accumulate;
+  const int nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
+  const int64_t mb = (M + 63) / 64;
+  if (mb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
+  const dim3 grid((unsigned)mb, (unsigned)((N + nt * 16 - 1) / (nt * 16)));
+  hipStream_t st = (hipStream_t)stream;
+#define TGCN_PROJ(NTV)                                                                               \
+  if (vec4) hipLaunchKernelGGL((project_kernel<NTV, true>), grid, dim3(kBlock), 0, st, p);             \
+  else hipLaunchKernelGGL((project_kernel<NTV, false>), grid, dim3(kBlock), 0, st, p);
+  if (nt == 1) { TGCN_PROJ(1) } else if (nt == 2) { TGCN_PROJ(2) } else { TGCN_PROJ(4) }
+#undef TGCN_PROJ
+  TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32");
+  return TGCN_OK;
+}
+
+int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int64_t Q, int64_t n, int32_t C) {
+  if (!in || !out || Q <= 0 || n <= 0 || C <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "relayout: bad argument");
+  if (C > 32) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "relayout: C=%d > 32", C);
+  const int64_t gy = (Q + kRelT - 1) / kRelT;
+  if (gy > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "relayout: Q too large");
+  const dim3 grid((unsigned)((n + kRelT - 1) / kRelT), (unsigned)gy);
+  hipLaunchKernelGGL(relayout_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, in, out, Q, n, (int)C);
+  TGCN_CHECK_LAUNCH("tgcn_relayout_qnc_to_nqc_f32");
+  return TGCN_OK;
+}
+
+// Workspace layout of the layer forward (all offsets 256-byte aligned):
+//   [xt]        n*q*C floats           (layout 1 only: re-laid input)
+//   [hop 1..K-1] (K-1) * qc*n*C floats
+//   [partial]   long-row segment scratch for one hop
+static void fwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t C, int32_t layout,
+                          int64_t qc, size_t* off_xt, size_t* off_hops, size_t* hop_bytes, size_t* off_part, size_t* total) {
+  size_t o = 0;
+  *off_xt = o;
+  if (layout == 1) o += align_up((size_t)q * n * C * sizeof(float), 256);
+  *off_hops = o;
+  *hop_bytes = align_up((size_t)qc * n * C * sizeof(float), 256);
+  o += (size_t)(K > 1 ? K - 1 : 0) * *hop_bytes;
+  *off_part = o;
+  const int32_t nb = layout == 1 ? 1 : (int32_t)qc;
+  const int32_t Crow = layout == 1 ? (int32_t)(q * C) : C;
+  o += align_up(tgcn_csr_hop_workspace_bytes(S, nb, Crow, 1), 256);
+  *total = o;
+}
+
+size_t tgcn_cheb_forward_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t C,
+                                         int32_t layout, int64_t q_chunk) {
+  if (!S || K < 1 || q < 1 || n < 1 || C < 1) return 0;
+  const int64_t qc = (layout == 1 || q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
+  size_t a, b, c, d, total;
+  fwd_ws_layout(S, K, q, n, C, layout, qc, &a, &b, &c, &d, &total);
+  return total;
+}
+
+int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t mode, int32_t K,
+                          int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
+                          const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
+                          void* workspace, size_t workspace_bytes) {
+  if (!A || !S || !x || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "forward: null operand");
+  if (K < 1 || q < 1 || n < 1 || C < 1 || N < 1 || n != A->n) TGCN_FAIL(TGCN_ERR_INVALID, "forward: bad shape (n=%lld, L is %lld)", (long long)n, (long long)A->n);
+  if (mode != 0 && mode != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward: mode %d", mode);
+  if (layout != 0 && layout != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward: layout %d", layout);
+  if (layout == 1 && (C > 32 || q * C > (int64_t)INT32_MAX)) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward: layout 1 needs C <= 32");
+  if (((uintptr_t)x & 15) || ((uintptr_t)workspace & 15)) TGCN_FAIL(TGCN_ERR_INVALID, "forward: x/workspace must be 16-byte aligned");
+  const int64_t qc = (layout == 1 || q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
+  size_t off_xt, off_hops, hop_bytes, off_part, total;
+  fwd_ws_layout(S, K, q, n, C, layout, qc, &off_xt, &off_hops, &hop_bytes, &off_part, &total);
+  if (total > 0 && (!workspace || workspace_bytes < total)) TGCN_FAIL(TGCN_ERR_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes, total);
+  char* ws = (char*)workspace;
+  float* part = (float*)(ws + off_part);
+  const size_t part_bytes = total - off_part;
+  const float* terms[kMaxTerms];
+  int64_t ldas[kMaxTerms];
+  int rc;
+
+  for (int64_t q0 = 0; q0 < q; q0 += qc) {
+    const int64_t qn = (q - q0 < qc) ? (q - q0) : qc;
+    // operand view of this pass
+    int32_t nb, Crow;
+    const float* x0;
+    if (layout == 1) {
+      float* xt = (float*)(ws + off_xt);
+      if ((rc = tgcn_relayout_qnc_to_nqc_f32(stream, x, xt, q, n, C)) != TGCN_OK) return rc;
+      x0 = xt; nb = 1; Crow = (int32_t)(q * C);
+    } else {
+      x0 = x + q0 * n * C; nb = (int32_t)qn; Crow = C;
+    }
+    const int64_t bs = (int64_t)n * Crow;
+    auto hop_ptr = [&](int k) -> float* { return k == 0 ? const_cast<float*>(x0) : (float*)(ws + off_hops + (size_t)(k - 1) * hop_bytes); };
+    for (int k = 1; k < K; ++k) {
+      tgcn_dense X = {hop_ptr(k - 1), bs, Crow};
+      tgcn_dense Y = {hop_ptr(k), bs, Crow};
+      if (mode == 0 || k == 1) {
+        rc = tgcn_csr_hop_f32(stream, A, S, nb, Crow, &X, nullptr, 1.f, 0.f, &Y, nullptr, part, part_bytes);
+      } else {
+        tgcn_dense Zd = {hop_ptr(k - 2), bs, Crow};
+        rc = tgcn_csr_hop_f32(stream, A, S, nb, Crow, &X, &Zd, 2.f, -1.f, &Y, nullptr, part, part_bytes);
+      }
+      if (rc != TGCN_OK) return rc;
+    }
+    // projection, in chunks of <= 32 terms
+    const int64_t M = (layout == 1) ? n * q : qn * n;
+    float* o0 = (layout == 1) ? out : out + q0 * n * N;
+    for (int k0 = 0; k0 < K; k0 += kMaxTerms) {
+      const int nt = (K - k0 < kMaxTerms) ? K - k0 : kMaxTerms;
+      for (int t = 0; t < nt; ++t) { terms[t] = hop_ptr(k0 + t); ldas[t] = C; }
+      const bool last = (k0 + nt >= K);
+      rc = tgcn_cheb_project_f32(stream, M, C, N, nt, terms, ldas, W + (size_t)k0 * C * N, last ? bias : nullptr,
+                                 last ? bias_kind : 0, n, layout == 1 ? q : 1, k0 > 0 ? 1 : 0, o0, N);
+      if (rc != TGCN_OK) return rc;
+    }
+  }
+  return TGCN_OK;
+}
+
+int tgcn_pool_max_f32(void* stream, const float* x, float* out, int32_t* idx, int64_t q, int64_t n, int32_t f, int32_t p) {
+  if (!x || !out || q <= 0 || n <= 0 || f <= 0 || p <= 0 || n % p != 0) TGCN_FAIL(TGCN_ERR_INVALID, "pool: bad argument (n=%lld p=%d)", (long long)n, p);
+  const int64_t total = q * (n / p) * f;
+  hipLaunchKernelGGL(pool_max_kernel, dim3(grid_1d(total)), dim3(kBlock), 0, (hipStream_t)stream, x, out, idx, total, (int)f, (int)p);
+  TGCN_CHECK_LAUNCH("tgcn_pool_max_f32");
+  return TGCN_OK;
+}
+
+int tgcn_pool_max_bwd_f32(void* stream, const float* grad_out, const int32_t* idx, float* grad_in, int64_t q, int64_t n, int32_t f, int32_t p) {
+  if (!grad_out || !idx || !grad_in || q <= 0 || n <= 0 || f <= 0 || p <= 0 || n % p != 0) TGCN_FAIL(TGCN_ERR_INVALID, "pool_bwd: bad argument");
+  const int64_t total = q * (n / p) * f;
+  hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(grid_1d(total)), dim3(kBlock), 0, (hipStream_t)stream, grad_out, idx, grad_in, total, (int)f, (int)p);
+  TGCN_CHECK_LAUNCH("tgcn_pool_max_bwd_f32");
+  return TGCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+"""Host side of the hot path: thin wrappers over the C ABI + the autograd function of the fused layer.
+
+Every product, sum and axpy of the forward runs in libtgcn_hip.so (include/tgcn_hip.h); torch supplies device
+memory, the stream and autograd bookkeeping.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .graph import GraphOperand
+
+MODE_POWER = 0      # dense-L classes: Xt[k] = 2 L^k x - Xt[k-2]  (tgcn/nn/gcn.py:75-78,150-153,233-236)
+MODE_CHEBYSHEV = 1  # edge-list classes: Tx_k = 2 L Tx_{k-1} - Tx_{k-2}  (gcn.py:427-432,524-528)
+BIAS_NONE, BIAS_CHANNEL, BIAS_VERTEX_CHANNEL = 0, 1, 2
+
+
+def _dense(t, batch_stride, row_stride):
+    return _lib.DenseStruct(t.data_ptr(), int(batch_stride), int(row_stride))
+
+
+def _aligned16(C_row, *tensors):
+    ok = C_row % 4 == 0
+    for t in tensors:
+        if t is not None:
+            ok = ok and t.data_ptr() % 16 == 0
+    return ok
+
+
+# ----------------------------------------------------------------------------------------- single ops
+def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=None):
+    """One hop on a (nb, n, C) contiguous operand:  S = L x;  y = alpha*S + beta*z;  optionally also S.
+    Returns y (and S when want_p)."""
+    _lib.require_device(x, z)
+    L = _lib.lib()
+    assert x.dim() == 3 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == op.n, (x.shape, op.n)
+    nb, n, Crow = x.shape
+    y = torch.empty_like(x) if out is None else out
+    p = (torch.empty_like(x) if p_out is None else p_out) if want_p else None
+    al = _aligned16(Crow, x, z, y, p)
+    sched = op.schedule_for(Crow, al)
+    ws_bytes = L.tgcn_csr_hop_workspace_bytes(C.byref(sched.struct), nb, Crow, 1 if al else 0)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    bs = n * Crow
+    X, Y = _dense(x, bs, Crow), _dense(y, bs, Crow)
+    Z = _dense(z, bs, Crow) if z is not None else None
+    P = _dense(p, bs, Crow) if p is not None else None
+    if z is not None:
+        assert z.shape == x.shape and z.is_contiguous()
+    _lib.check(L.tgcn_csr_hop_f32(_lib.stream_ptr(), C.byref(op.struct), C.byref(sched.struct), nb, Crow, C.byref(X),
+                                  C.byref(Z) if Z is not None else None, float(alpha), float(beta), C.byref(Y),
+                                  C.byref(P) if P is not None else None, _lib.ptr(ws), ws.numel()))
+    return (y, p) if want_p else y
+
+
+def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
+    """out[r(m)] = sum_t terms[t][m, :] @ W[t] + bias; terms: list of (M, Kc) contiguous; W: (T, Kc, N)."""
+    _lib.require_device(W, *terms)
+    L = _lib.lib()
+    T = len(terms)
+    M, Kc = terms[0].shape
+    N = W.shape[-1]
+    W = W.reshape(T * Kc, N).contiguous()
+    rows_out = M
+    if out is None:
+        out = torch.empty((rows_out, N), dtype=torch.float32, device=W.device)
+    b = bias.contiguous() if bias is not None else None
+    for t0 in range(0, T, 32):
+        nt = min(32, T - t0)
+        last = t0 + nt >= T
+        a = (C.c_void_p * nt)(*[terms[t0 + i].data_ptr() for i in range(nt)])
+        lda = (C.c_int64 * nt)(*[terms[t0 + i].stride(0) for i in range(nt)])
+        _lib.check(L.tgcn_cheb_project_f32(_lib.stream_ptr(), M, Kc, N, nt, a, lda, _lib.ptr(W[t0 * Kc:]),
+                                           _lib.ptr(b) if last else None, bias_kind if last else 0, n_vertices,
+                                           interleave, 1 if t0 > 0 else 0, _lib.ptr(out), N))
+    return out
+
+
+def choose_layout(q, n, C_row):
+    """layout 1 (re-lay x to one long row per vertex) when per-sample rows are short: gathers then move
+    q*C contiguous floats per neighbour instead of C."""
+    return 1 if (C_row < 32 and q > 1) else 0
+
+
+def choose_q_chunk(q, n, C_row):
+    """Samples per pass on layout 0: operands that overflow the caches anyway go one sample at a time, so a
+    pass's gather working set is one (n, C) slab (and the hop workspace stays small)."""
+    per_q = n * C_row * 4
+    return int(max(1, min(q, (64 << 20) // max(per_q, 1))))
+
+
+def cheb_forward_raw(op, x3, Wt, bias, bias_kind, mode, K, layout=None, q_chunk=None):
+    """Fused layer forward through tgcn_cheb_forward_f32.  x3: (q, n, C) contiguous; Wt: (K*C, N)."""
+    _lib.require_device(x3, Wt, bias)
+    L = _lib.lib()
+    q, n, Crow = x3.shape
+    N = Wt.shape[1]
+    assert x3.is_contiguous() and Wt.is_contiguous() and Wt.shape[0] == K * Crow and n == op.n
+    if layout is None:
+        layout = choose_layout(q, n, Crow)
+    if q_chunk is None:
+        q_chunk = choose_q_chunk(q, n, Crow)
+    hop_C = q * Crow if layout == 1 else Crow
+    sched = op.schedule_for(hop_C, hop_C % 4 == 0)
+    ws_bytes = L.tgcn_cheb_forward_workspace_bytes(C.byref(sched.struct), K, q, n, Crow, layout, q_chunk)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
+    out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
+    _lib.check(L.tgcn_cheb_forward_f32(_lib.stream_ptr(), C.byref(op.struct), C.byref(sched.struct), mode, K, q, n, Crow,
+                                       N, _lib.ptr(x3), _lib.ptr(Wt), _lib.ptr(bias), bias_kind, _lib.ptr(out), layout,
+                                       q_chunk, _lib.ptr(ws), ws.numel()))
+    return out
+
+
+def cheb_stack(op, x3, K, mode):
+    """The (K, q, n, C) stack `_chebyshev` / `_time_chebyshev` return (gcn.py:52-79,126-154,208-237), or the
+    true-recurrence stack for mode 1.  Materialising path: every hop writes its slice of the stack."""
+    _lib.require_device(x3)
+    q, n, Crow = x3.shape
+    st = torch.empty((K, q, n, Crow), dtype=torch.float32, device=x3.device)
+    st[0].copy_(x3)
+    if K > 1:
+        csr_hop(op, st[0], out=st[1])
+    p_prev = st[1] if K > 1 else None
+    for k in range(2, K):
+        if mode == MODE_POWER:      # P_k = L P_{k-1} (hidden chain), Xt[k] = 2 P_k - Xt[k-2]
+            _, p_prev = csr_hop(op, p_prev, z=st[k - 2], alpha=2.0, beta=-1.0, want_p=True, out=st[k])
+        else:
+            csr_hop(op, st[k - 1], z=st[k - 2], alpha=2.0, beta=-1.0, out=st[k])
+    return st
+
+
+def power_fold_matrix(K, device=None, dtype=torch.float32):
+    """c[k, j] with Xt[k] = sum_j c[k, j] L^j x for the reference_power recursion: c[0]=e0, c[1]=e1,
+    c[k] = 2 e_k - c[k-2].  Folding it into the weight (W'_j = sum_k c[k,j] W_k) turns the layer into one
+    monomial chain: no subtrahend reads, no second output (verified there to <= 6.3e-7)."""
+    c = torch.zeros(K, K, dtype=torch.float64)
+    for k in range(K):
+        c[k, k] = 1.0 if k < 2 else 2.0
+        if k >= 2:
+            c[k] -= c[k - 2]
+    return c.to(device=device, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------------------- autograd
+class ChebLayerFn(torch.autograd.Function):
+    """out = sum_k T_k x W_k + bias with T_k given by `mode`; x3 (q,n,C), Wt (K, C, N) already folded for
+    MODE_POWER.  Backward: the same HIP hop kernel on L^T for dx (Horner / Clenshaw), library GEMMs for the
+    dense contractions."""
+
+    @staticmethod
+    def forward(ctx, x3, Wt, bias, op, mode, bias_kind):
+        K, Crow, N = Wt.shape
+        out = cheb_forward_raw(op, x3.contiguous(), Wt.reshape(K * Crow, N).contiguous(),
+                               bias.contiguous() if bias is not None else None, bias_kind, mode, K)
+        ctx.save_for_backward(x3, Wt)
+        ctx.op, ctx.mode, ctx.bias_kind = op, mode, bias_kind
+        ctx.bias_shape = None if bias is None else bias.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, Wt = ctx.saved_tensors
+        op, mode = ctx.op, ctx.mode
+        K, Crow, N = Wt.shape
+        g = g.contiguous()
+        gx = gW = gb = None
+        if ctx.needs_input_grad[1]:
+            x3c = x3.contiguous()
+            basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
+            gW = torch.einsum("kqnc,qng->kcg", basis, g)
+        if ctx.needs_input_grad[0]:
+            opT = op.transpose()
+            G = torch.einsum("qng,kcg->kqnc", g, Wt).contiguous()      # G_k = g W_k^T
+            if mode == MODE_POWER:                                       # Horner: b = G_j + L^T b
+                b = G[K - 1]
+                for j in range(K - 2, -1, -1):
+                    b = csr_hop(opT, b, z=G[j], alpha=1.0, beta=1.0)
+                gx = b
+            elif K == 1:
+                gx = G[0]
+            else:                                                        # Clenshaw on L^T
+                b1 = torch.zeros_like(G[0])
+                b2 = torch.zeros_like(G[0])
+                for k in range(K - 1, 0, -1):
+                    t = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0)
+                    t.add_(G[k])
+                    b1, b2 = t, b1
+                gx = csr_hop(opT, b1, z=b2, alpha=1.0, beta=-1.0)
+                gx.add_(G[0])
+        if ctx.bias_shape is not None and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=(0, 1)) if ctx.bias_kind == BIAS_CHANNEL else g.sum(dim=0)
+            gb = gb.reshape(ctx.bias_shape)
+        return gx, gW, gb, None, None, None
+
+
+def _monomial_stack(op, x3, K):
+    st = torch.empty((K,) + tuple(x3.shape), dtype=torch.float32, device=x3.device)
+    st[0].copy_(x3)
+    for k in range(1, K):
+        csr_hop(op, st[k - 1], out=st[k])
+    return st
+
+
+def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode):
+    """Differentiable fused layer.  weight_kcn: (K, C, N) in the REFERENCE basis; for MODE_POWER it is folded to
+    the monomial basis here with a differentiable einsum, so autograd returns the gradient in the reference basis."""
+    K = weight_kcn.shape[0]
+    if mode == MODE_POWER and K > 2:
+        c = power_fold_matrix(K, weight_kcn.device)
+        weight_kcn = torch.einsum("kj,kcn->jcn", c, weight_kcn)
+    return ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind)
+
+
+# ----------------------------------------------------------------------------------------- pooling
+class PoolMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        _lib.require_device(x)
+        x = x.contiguous()
+        q, n, f = x.shape
+        out = torch.empty((q, n // p, f), dtype=torch.float32, device=x.device)
+        idx = torch.empty((q, n // p, f), dtype=torch.int32, device=x.device)
+        _lib.check(_lib.lib().tgcn_pool_max_f32(_lib.stream_ptr(), _lib.ptr(x), _lib.ptr(out), _lib.ptr(idx), q, n, f, p))
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.p = (q, n, f), p
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        q, n, f = ctx.shape
+        gi = torch.empty((q, n, f), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().tgcn_pool_max_bwd_f32(_lib.stream_ptr(), _lib.ptr(g.contiguous()), _lib.ptr(idx), _lib.ptr(gi),
+                                                    q, n, f, ctx.p))
+        return gi, None

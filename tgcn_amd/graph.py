@@ -1,0 +1,184 @@
+"""Graph operand of the Chebyshev layers: L-hat as device CSR + nnz-balanced row-block schedules.
+
+Built ONCE per operand (the reference re-does `L.to(device)` and the degree normalisation on every forward:
+tgcn/nn/gcn.py:141,223 and :408-413,505-510) and cached by the modules.  The preparation below is index
+plumbing on torch tensors (sort / cumsum / searchsorted); every flop of the layer runs in libtgcn_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+LONG_THRESH = 256       # stored entries one lane group sums in a row before the row is cut into segments
+ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
+MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
+
+
+def _as_i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+class Schedule:
+    """nnz-balanced row blocks for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
+
+    def __init__(self, rowptr, n, lanes_per_row, long_thresh=LONG_THRESH):
+        dev = rowptr.device
+        gpb = 256 // lanes_per_row
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        is_long = deg > long_thresh
+        cost = torch.where(is_long, torch.zeros_like(deg), deg) + ROW_COST
+        cum = torch.cumsum(cost, 0)
+        total = int(cum[-1].item())
+        target = max(gpb * 16, min(gpb * 256, -(-total // MAX_BLOCKS_HINT)))
+        nblk = max(1, -(-total // target))
+        if nblk > 1:
+            marks = torch.arange(1, nblk, device=dev, dtype=torch.int64) * target
+            inner = (torch.searchsorted(cum, marks) + 1).clamp_(max=n)
+        else:
+            inner = torch.zeros(0, dtype=torch.int64, device=dev)
+        self.blk_row = _as_i32(torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), inner,
+                                          torch.full((1,), n, dtype=torch.int64, device=dev)]))
+        self.nblk = nblk
+        long_rows = is_long.nonzero().flatten()
+        self.nlong = int(long_rows.numel())
+        if self.nlong:
+            nsegs = (deg[long_rows] + long_thresh - 1) // long_thresh
+            first = torch.cumsum(nsegs, 0) - nsegs
+            self.nseg = int(nsegs.sum().item())
+            seg_row = torch.repeat_interleave(long_rows, nsegs)
+            within = torch.arange(self.nseg, device=dev, dtype=torch.int64) - torch.repeat_interleave(first, nsegs)
+            e0 = rowptr[seg_row].to(torch.int64) + within * long_thresh
+            e1 = torch.minimum(e0 + long_thresh, rowptr[seg_row + 1].to(torch.int64))
+            self.seg_row, self.seg_e0, self.seg_e1 = _as_i32(seg_row), _as_i32(e0), _as_i32(e1)
+            self.long_row = _as_i32(long_rows)
+            self.long_seg = _as_i32(torch.cat([first, first[-1:] + nsegs[-1:]]))
+        else:
+            self.nseg = 0
+            z = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.seg_row = self.seg_e0 = self.seg_e1 = self.long_row = z
+            self.long_seg = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.lanes_per_row = lanes_per_row
+        self.long_thresh = long_thresh
+        self.struct = _lib.SchedStruct(lanes_per_row, long_thresh, self.nblk, self.nseg, self.nlong, 0,
+                                       self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
+                                       self.seg_e1.data_ptr(), self.long_row.data_ptr(), self.long_seg.data_ptr())
+
+
+class GraphOperand:
+    """L-hat (n x n) in CSR with 8-byte packed {int32 col, float val} entries, on one device."""
+
+    def __init__(self, n, rowptr, col, val):
+        assert rowptr.dtype == torch.int32 and col.dtype == torch.int32 and val.dtype == torch.float32
+        self.n = int(n)
+        self.nnz = int(col.numel())
+        if self.nnz >= 2 ** 31 - 1 or self.n >= 2 ** 31 - 1:
+            raise _lib.TgcnError("graph operand outside the int32 index range (n=%d nnz=%d)" % (self.n, self.nnz))
+        self.device = rowptr.device
+        self.rowptr = rowptr.contiguous()
+        edges = torch.empty((max(self.nnz, 1), 2), dtype=torch.int32, device=self.device)
+        if self.nnz:
+            edges[:, 0] = col
+            edges[:, 1] = val.view(torch.int32)
+        self.edges = edges
+        self.struct = _lib.CsrStruct(self.n, self.nnz, self.rowptr.data_ptr(), self.edges.data_ptr())
+        self._sched = {}
+        self._transpose = None
+
+    # ------------------------------------------------------------------ constructors
+    @staticmethod
+    def from_coo(n, row, col, val, device=None):
+        """Entries may come in any order; duplicates stay separate entries (their sum is what
+        scatter_add computes, tgcn/nn/gcn.py:308,343)."""
+        device = row.device if device is None else torch.device(device)
+        row = row.to(device=device, dtype=torch.int64)
+        col = col.to(device=device, dtype=torch.int64)
+        val = val.to(device=device, dtype=torch.float32)
+        order = torch.argsort(row * n + col)
+        counts = torch.bincount(row, minlength=n)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        return GraphOperand(n, _as_i32(rowptr), _as_i32(col[order]), val[order].contiguous())
+
+    @staticmethod
+    def from_dense(L, device=None):
+        """Dense (n, n) tensor / ndarray as passed to TGCNCheb / TGCNCheb_H / GCNCheb (gcn.py:18,92,168)."""
+        L = torch.as_tensor(L)
+        device = L.device if device is None else torch.device(device)
+        L = L.to(device=device, dtype=torch.float32)
+        idx = L.nonzero()
+        return GraphOperand.from_coo(L.shape[0], idx[:, 0], idx[:, 1], L[idx[:, 0], idx[:, 1]], device)
+
+    @staticmethod
+    def from_any(L, device):
+        """Dense tensor, torch sparse COO/CSR (gcn_matmul accepts those, gcn_matmul.py:154), scipy sparse or ndarray."""
+        if isinstance(L, GraphOperand):
+            return L if L.device == torch.device(device) else L.to(device)
+        if isinstance(L, torch.Tensor):
+            if L.layout == torch.sparse_coo:
+                Lc = L.coalesce()
+                i = Lc.indices()
+                return GraphOperand.from_coo(L.shape[0], i[0], i[1], Lc.values(), device)
+            if L.layout == torch.sparse_csr:
+                Lc = L.to_sparse_coo().coalesce()
+                i = Lc.indices()
+                return GraphOperand.from_coo(L.shape[0], i[0], i[1], Lc.values(), device)
+            return GraphOperand.from_dense(L, device)
+        if hasattr(L, "tocoo"):                                        # scipy.sparse
+            coo = L.tocoo()
+            return GraphOperand.from_coo(coo.shape[0], torch.as_tensor(coo.row), torch.as_tensor(coo.col),
+                                         torch.as_tensor(coo.data), device)
+        return GraphOperand.from_dense(torch.as_tensor(L), device)
+
+    @staticmethod
+    def from_edge_index(edge_index, edge_weight, n, device=None):
+        """ChebConv / ChebTimeConv operand (tgcn/nn/gcn.py:398-413, :495-510): self loops removed,
+        deg = number of edges per SOURCE vertex (unweighted), lap_e = -deg^-1/2[row] * w_e * deg^-1/2[col],
+        deg^-1/2 = 0 for isolated vertices."""
+        device = edge_index.device if device is None else torch.device(device)
+        row, col = edge_index[0].to(device), edge_index[1].to(device)
+        keep = row != col
+        row, col = row[keep], col[keep]
+        if edge_weight is None:
+            w = torch.ones(row.numel(), dtype=torch.float32, device=device)
+        else:
+            w = edge_weight.reshape(-1).to(device=device, dtype=torch.float32)[keep]
+        deg = torch.bincount(row, minlength=n).to(torch.float32)
+        dis = deg.pow(-0.5)
+        dis[torch.isinf(dis)] = 0
+        lap = -dis[row] * w * dis[col]
+        return GraphOperand.from_coo(n, row, col, lap, device)
+
+    # ------------------------------------------------------------------ derived operands
+    def coo(self):
+        counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        row = torch.repeat_interleave(torch.arange(self.n, device=self.device), counts)
+        e = self.edges[: self.nnz]
+        return row, e[:, 0].to(torch.int64), e[:, 1].contiguous().view(torch.float32)
+
+    def transpose(self):
+        """L-hat^T, for the input gradient (L-hat is symmetric for the dense-L classes' usual operand, but
+        ChebConv normalises by the source degree only, so the general case is kept)."""
+        if self._transpose is None:
+            row, col, val = self.coo()
+            self._transpose = GraphOperand.from_coo(self.n, col, row, val, self.device)
+            self._transpose._transpose = self
+        return self._transpose
+
+    def to(self, device):
+        row, col, val = self.coo()
+        return GraphOperand.from_coo(self.n, row, col, val, device)
+
+    def schedule(self, lanes_per_row):
+        s = self._sched.get(lanes_per_row)
+        if s is None:
+            s = self._sched[lanes_per_row] = Schedule(self.rowptr, self.n, lanes_per_row)
+        return s
+
+    def schedule_for(self, C_row, aligned16=True):
+        return self.schedule(_lib.lib().tgcn_hop_lanes_per_row(int(C_row), 1 if aligned16 else 0))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        row, col, val = self.coo()
+        return sp.coo_matrix((val.cpu().numpy(), (row.cpu().numpy(), col.cpu().numpy())), shape=(self.n, self.n)).tocsr()

@@ -1,0 +1,260 @@
+"""Drop-in modules: the class surface of tgcn/nn/gcn.py (and tgcn/nn/gcn_matmul.py) on the HIP path.
+
+Same constructor / forward signatures, parameter names, shapes and initialisation as the reference
+(state_dict compatible); `L` stays a plain attribute (not saved, not moved by .to(), gcn.py:18,92,168).
+The forward of every class is one call into libtgcn_hip.so (K-1 CSR hops + MFMA projection); nothing here
+falls back to torch ops or the CPU.
+"""
+import math
+
+import torch
+from torch.nn import Parameter
+
+from . import functional as F
+from .graph import GraphOperand
+
+
+def uniform(size, tensor):
+    """U(-1/sqrt(size), 1/sqrt(size)) in place; None is ignored (reference: tgcn/nn/gcn.py:240-243)."""
+    bound = 1.0 / math.sqrt(size)
+    if tensor is not None:
+        tensor.data.uniform_(-bound, bound)
+
+
+def gcn_pool(x):
+    """Max over pairs of consecutive vertices, (q,n,f)->(q,n/2,f) (reference: gcn.py:246-249)."""
+    return F.PoolMaxFn.apply(x, 2)
+
+
+def gcn_pool_4(x):
+    """Max over 4 consecutive vertices (reference: gcn.py:252-255)."""
+    return F.PoolMaxFn.apply(x, 4)
+
+
+class _OperandCache:
+    """One GraphOperand per (source object identity, version, device): DataParallel replicas on other devices
+    and in-place edits of L / edge_index get their own."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, key, build):
+        op = self._d.get(key)
+        if op is None:
+            if len(self._d) > 16:
+                self._d.clear()
+            op = self._d[key] = build()
+        return op
+
+
+def _tensor_key(t):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+
+class _DenseLBase(torch.nn.Module):
+    """Shared plumbing of the three classes that take L in the constructor."""
+
+    def _operand(self, device):
+        L = self.L
+        key = (id(L), getattr(L, "_version", 0), str(device))
+        return self._ops.get(key, lambda: GraphOperand.from_any(L, device))
+
+    def _num_vertices(self):
+        return self.L.shape[0] if hasattr(self.L, "shape") else self.L[0].shape[0]
+
+    def reset_parameters(self):
+        size = self.in_channels * self.weight.size(0)
+        uniform(size, self.weight)
+        uniform(size, self.bias)
+
+    def __repr__(self):
+        return '{}({}, {}, filter_order={})'.format(self.__class__.__name__, self.in_channels, self.out_channels,
+                                                    self.weight.size(0))
+
+    def _stack(self, X4):
+        """X4: (q, n, h, f) or (q, n, f) -> stack (K, ...) in the reference_power recursion."""
+        sh = X4.shape
+        x3 = X4.reshape(sh[0], sh[1], -1).float().contiguous()
+        st = F.cheb_stack(self._operand(x3.device), x3, self.filter_order, F.MODE_POWER)
+        return st.reshape((self.filter_order,) + tuple(sh))
+
+
+class TGCNCheb(_DenseLBase):
+    """reference: tgcn/nn/gcn.py:8-79.  x (q, n, f) -> (q, n, g); weight (K, f, g); bias (1, n, g)."""
+
+    def __init__(self, L, in_channels, out_channels, filter_order, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = Parameter(torch.Tensor(filter_order, in_channels, out_channels))
+        self.L = L
+        self.filter_order = filter_order
+        self._ops = _OperandCache()
+        if bias:
+            self.bias = Parameter(torch.Tensor(1, self._num_vertices(), out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def forward(self, x):
+        x3 = x.float().contiguous()
+        return F.cheb_layer(self._operand(x3.device), x3, self.weight, self.bias,
+                            F.BIAS_NONE if self.bias is None else F.BIAS_VERTEX_CHANNEL, F.MODE_POWER)
+
+    def _time_chebyshev(self, X):
+        return self._stack(X)
+
+
+class TGCNCheb_H(_DenseLBase):
+    """reference: tgcn/nn/gcn.py:82-154.  x (q, n, h[, f]) -> (q, n, g); weight (K, H, f, g); bias (1, n, g)."""
+
+    def __init__(self, L, in_channels, out_channels, filter_order, horizon, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = Parameter(torch.Tensor(filter_order, horizon, in_channels, out_channels))
+        self.L = L
+        self.filter_order = filter_order
+        self._ops = _OperandCache()
+        if bias:
+            self.bias = Parameter(torch.Tensor(1, self._num_vertices(), out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def forward(self, x):
+        if x.dim() == 3:
+            x = x.unsqueeze(3)
+        q, n, h, f = x.shape
+        x3 = x.float().reshape(q, n, h * f).contiguous()
+        W = self.weight.reshape(self.weight.shape[0], h * f, self.out_channels)
+        return F.cheb_layer(self._operand(x3.device), x3, W, self.bias,
+                            F.BIAS_NONE if self.bias is None else F.BIAS_VERTEX_CHANNEL, F.MODE_POWER)
+
+    def _time_chebyshev(self, X):
+        if X.dim() == 3:
+            X = X.unsqueeze(3)
+        return self._stack(X)
+
+
+class GCNCheb(_DenseLBase):
+    """reference: tgcn/nn/gcn.py:158-237.  x (q, n[, f]) -> (q, n, g); weight (K, f, g); bias (1, 1, g)."""
+
+    def __init__(self, L, in_channels, out_channels, filter_order, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = Parameter(torch.Tensor(filter_order, in_channels, out_channels))
+        self.L = L
+        self.filter_order = filter_order
+        self._ops = _OperandCache()
+        if bias:
+            self.bias = Parameter(torch.Tensor(1, 1, out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def forward(self, x):
+        if x.dim() == 2:
+            x = x.unsqueeze(2)
+        x3 = x.float().contiguous()
+        return F.cheb_layer(self._operand(x3.device), x3, self.weight, self.bias,
+                            F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_POWER)
+
+    def _chebyshev(self, X):
+        if X.dim() == 2:
+            X = X.unsqueeze(2)
+        return self._stack(X)
+
+
+# ------------------------------------------------------------------------------------ COO helpers
+_spmm_ops = _OperandCache()
+
+
+def _coo_operand(index, value, m, device):
+    key = (_tensor_key(index), _tensor_key(value), int(m), str(device))
+    return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value, device))
+
+
+def spmm(index, value, m, matrix):
+    """out[r] += v_e * matrix[c] over axis 0 (reference: gcn.py:258-278)."""
+    matrix = matrix if matrix.dim() > 1 else matrix.unsqueeze(-1)
+    op = _coo_operand(index, value, m, matrix.device)
+    x3 = matrix.float().reshape(1, matrix.shape[0], -1).contiguous()
+    return F.csr_hop(op, x3).reshape((m,) + tuple(matrix.shape[1:]))
+
+
+def spmm_batch_2(index, value, m, matrix):
+    """Same product over axis 1 of (q, n[, f]) (reference: gcn.py:281-310; a 2-D input gains a channel axis)."""
+    if matrix.dim() == 2:
+        matrix = matrix.unsqueeze(-1)
+    return spmm_batch_3(index, value, m, matrix)
+
+
+def spmm_batch_3(index, value, m, matrix):
+    """Same product over axis 1 of (q, n, h, f) (reference: gcn.py:313-345)."""
+    op = _coo_operand(index, value, m, matrix.device)
+    sh = matrix.shape
+    x3 = matrix.float().reshape(sh[0], sh[1], -1).contiguous()
+    return F.csr_hop(op, x3).reshape((sh[0], m) + tuple(sh[2:]))
+
+
+# ------------------------------------------------------------------------------------ edge-list classes
+class _EdgeBase(torch.nn.Module):
+    def _operand(self, x, edge_index, edge_weight):
+        n = x.size(1)
+        if edge_weight is not None:
+            assert edge_weight.reshape(-1).size(0) == edge_index.size(1)
+        key = (_tensor_key(edge_index), _tensor_key(edge_weight), n, str(x.device))
+        return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, edge_weight, n, x.device))
+
+    def reset_parameters(self):
+        size = self.in_channels * self.weight.size(0)
+        uniform(size, self.weight)
+        uniform(size, self.bias)
+
+    def __repr__(self):
+        return '{}({}, {}, K={})'.format(self.__class__.__name__, self.in_channels, self.out_channels, self.weight.size(0))
+
+
+class ChebConv(_EdgeBase):
+    """reference: tgcn/nn/gcn.py:348-442.  forward(x (q,n[,f]), edge_index (2,E), edge_weight=None) -> (q,n,g)."""
+
+    def __init__(self, in_channels, out_channels, K, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = Parameter(torch.Tensor(K, in_channels, out_channels))
+        self._ops = _OperandCache()
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight=None):
+        op = self._operand(x, edge_index, edge_weight)
+        if x.dim() < 3:
+            x = x.unsqueeze(-1)
+        return F.cheb_layer(op, x.float().contiguous(), self.weight, self.bias,
+                            F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)
+
+
+class ChebTimeConv(_EdgeBase):
+    """reference: tgcn/nn/gcn.py:445-538.  forward(x (q,n,h[,f]), edge_index, edge_weight=None) -> (q,n,g)."""
+
+    def __init__(self, in_channels, out_channels, K, H, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = Parameter(torch.Tensor(K, H, in_channels, out_channels))
+        self._ops = _OperandCache()
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight=None):
+        op = self._operand(x, edge_index, edge_weight)
+        if x.dim() < 4:
+            x = x.unsqueeze(-1)
+        q, n, h, f = x.shape
+        W = self.weight.reshape(self.weight.shape[0], h * f, self.out_channels)
+        return F.cheb_layer(op, x.float().reshape(q, n, h * f).contiguous(), W, self.bias,
+                            F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)

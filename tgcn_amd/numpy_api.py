@@ -1,0 +1,33 @@
+"""numpy twin of the recursion for the autograd/numpy scripts: gcn.graph.chebyshev(L, X, K)
+(reference: gcn/graph.py:241-283), computed on the GPU through the same HIP hop kernel."""
+import numpy as np
+import torch
+
+from . import functional as F
+from .graph import GraphOperand
+
+_cache = {}
+
+
+def chebyshev(L, X, K, device="cuda"):
+    """2-D X (M, N): Xt[0]=X, Xt[1]=L X, Xt[k]=2 L^k X - Xt[k-2]  (graph.py:256-265); returns (K, M, N) in L.dtype.
+    Arithmetic is fp32 on the device (the reference computes in L.dtype; fp64 operands are rounded to fp32).
+    N-D X: the reference reshapes X to (X.shape[1], -1) WITHOUT permuting (graph.py:267-283), which mixes samples;
+    that branch is reproduced literally (true recurrence on the reshaped matrix) because callers depend on it."""
+    X = getattr(X, "_value", X)          # autograd boxes are unwrapped like graph.py:249-252
+    X = np.asarray(X)
+    key = (id(L), getattr(L, "nnz", None), str(device))
+    op = _cache.get(key)
+    if op is None:
+        if len(_cache) > 8:
+            _cache.clear()
+        op = _cache[key] = GraphOperand.from_any(L, device)
+    out_dtype = L.dtype if hasattr(L, "dtype") else X.dtype
+    if X.ndim == 2:
+        x3 = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32), device=device).unsqueeze(0)
+        st = F.cheb_stack(op, x3, K, F.MODE_POWER)[:, 0]
+        return st.cpu().numpy().astype(out_dtype, copy=False)
+    sh = X.shape
+    x3 = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32).reshape(1, sh[1], -1), device=device)
+    st = F.cheb_stack(op, x3, K, F.MODE_CHEBYSHEV)[:, 0]
+    return st.cpu().numpy().astype(out_dtype, copy=False).reshape((K,) + sh)
