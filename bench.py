@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- Cheb-TGCN forward on MI355X: G edge.timesteps/s + achieved HBM GB/s against the roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg5|cfg4|cfg3|cfg2] [--labeling random|degree|natural]
+
+A "step" is ONE forward of the layer over one batch of synthetic input resident in HBM:
+  cfg5 (default, BASELINE.json's metric): R-MAT n=10M / nnz=160M, TGCNCheb(L, 64, 64, K=5) semantics with q=T=16
+        time steps  -> 4 hops x 16 time steps of CSR x (n x 64) + the (K*64) x 64 projection.
+  cfg4: sheet mesh n=90k / nnz~0.9M, TGCNCheb_H(L, 1, 32, 5, 1200), q=1.
+  cfg3: MNIST grid n=784, TGCNCheb_H(L, 1, 64, 5, 28), q=64.      cfg2: GCNCheb(L, 1, 64, 5), q=128.
+N > 1 (driver-launched with torch.distributed.run): the path shards by time step -- every rank holds the CSR and
+processes its own q time steps, no data-path collective -- weak scaling; value is the whole-job aggregate.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = hop_kernel,
+algorithmic bytes per launch / mean launch duration from hipEvents recorded around every hop launch of the timed
+steps) and `cpu_baseline` (oracle/cheb_ref.c, OpenMP, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
+
+
+def build_workload(name, labeling, device, n_override=None, nnz_override=None):
+    from tools import synth
+    from tgcn_amd.graph import GraphOperand
+    if name == "cfg5":
+        n, nnz = n_override or 10_000_000, nnz_override or 160_000_000
+        _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling=labeling, device=device)
+        spec = dict(cls="TGCNCheb", q=16, H=1, f=64, g=64, K=5,
+                    desc="R-MAT(0.57,0.19,0.19,0.05) n=%d nnz=%d %s labels, TGCNCheb(L,64,64,K=5), q=T=16" % (n, nnz, labeling))
+    elif name == "cfg4":
+        n, row, col, val = synth.sheet_mesh(300, device=device)
+        spec = dict(cls="TGCNCheb_H", q=1, H=1200, f=1, g=32, K=5, desc="sheet mesh n=90000 nnz=%d, TGCNCheb_H(L,1,32,5,1200), q=1" % row.numel())
+    elif name in ("cfg3", "cfg2"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "GCNCheb_grid784_q3_f1_g8_K5_x2d.npz"))
+        n = int(z["n"])
+        rowptr = torch.as_tensor(z["rowptr"])
+        row = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1]).to(device)
+        col, val = torch.as_tensor(z["col"]).long().to(device), torch.as_tensor(z["val"]).to(device)
+        if name == "cfg3":
+            spec = dict(cls="TGCNCheb_H", q=64, H=28, f=1, g=64, K=5, desc="MNIST 8-NN grid n=784 nnz=6396, TGCNCheb_H(L,1,64,5,28), q=64")
+        else:
+            spec = dict(cls="GCNCheb", q=128, H=1, f=1, g=64, K=5, desc="MNIST 8-NN grid n=784 nnz=6396, GCNCheb(L,1,64,5), q=128")
+    else:
+        raise SystemExit("unknown workload " + name)
+    op = GraphOperand.from_coo(n, row, col, val, device)
+    del row, col, val
+    return op, spec
+
+
+def make_layer(op, spec, device):
+    import tgcn_amd
+    torch.manual_seed(1)
+    if spec["cls"] == "TGCNCheb":
+        layer = tgcn_amd.TGCNCheb(op, spec["f"], spec["g"], spec["K"])
+    elif spec["cls"] == "TGCNCheb_H":
+        layer = tgcn_amd.TGCNCheb_H(op, spec["f"], spec["g"], spec["K"], spec["H"])
+    else:
+        layer = tgcn_amd.GCNCheb(op, spec["f"], spec["g"], spec["K"])
+    return layer.to(device)
+
+
+def make_input(op, spec, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    q, n = spec["q"], op.n
+    if spec["cls"] == "TGCNCheb":
+        shape = (q, n, spec["f"])
+    elif spec["cls"] == "TGCNCheb_H":
+        shape = (q, n, spec["H"]) if spec["f"] == 1 else (q, n, spec["H"], spec["f"])
+    else:
+        shape = (q, n) if spec["f"] == 1 else (q, n, spec["f"])
+    return torch.randn(shape, device=device, generator=g)
+
+
+def cpu_baseline(op, spec, layer, x, budget_q=1):
+    """oracle/cheb_ref.c (reference algorithm: full stack + unfolded weights) on the host cores, on `budget_q`
+    of the q samples of the same workload."""
+    from oracle import c_port
+    row, col, val = op.coo()
+    rowptr = op.rowptr.cpu().numpy()
+    col = col.to(torch.int32).cpu().numpy()
+    val = val.cpu().numpy()
+    q = min(budget_q, spec["q"])
+    xs = x[:q].reshape(q, op.n, -1).float().cpu().numpy()
+    K = spec["K"]
+    W = layer.weight.detach().reshape(K, -1, spec["g"]).cpu().numpy()
+    b = layer.bias.detach().reshape(-1).cpu().numpy()
+    kind = 1 if spec["cls"] == "GCNCheb" else 2
+    t0 = time.perf_counter()
+    out = c_port.forward(0, rowptr, col, val, xs, W, b, kind)
+    dt = time.perf_counter() - t0
+    units = op.nnz * (K - 1) * q * spec["H"]
+    return out, dict(value=units / dt / 1e9, unit="G edge.timesteps/s", cores=c_port.threads(), kind="port",
+                     sample="%d of %d samples of the same workload, full K=%d forward, oracle/cheb_ref.c OpenMP, %.1f s" % (q, spec["q"], K, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg5")
+    ap.add_argument("--labeling", default="random")
+    ap.add_argument("--n", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
+    ap.add_argument("--nnz", type=int, default=None)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from tgcn_amd import _lib
+    op, spec = build_workload(args.workload, args.labeling, device, args.n, args.nnz)
+    layer = make_layer(op, spec, device)
+    x = make_input(op, spec, device, seed=rank)
+    K, q, H = spec["K"], spec["q"], spec["H"]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = layer(x)
+        sync_all()
+        _lib.profile_start(65536)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = layer(x)
+        sync_all()
+        dt = time.perf_counter() - t0
+        prof = _lib.profile_stop(65536)
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    units_per_step = op.nnz * (K - 1) * q * H            # edge.timesteps per forward per rank
+    value = world * units_per_step * args.steps / dt / 1e9
+
+    # ---- roofline of the dominant kernel (hop_kernel): algorithmic bytes per launch / mean launch duration
+    hop_ms = [ms for kind, ms in prof if kind == 0]
+    proj_ms = [ms for kind, ms in prof if kind == 2]
+    C_row = H * spec["f"]
+    F = q * C_row
+    bytes_recursion = (K - 1) * (8 * op.nnz + 4 * (op.n + 1) + 8 * op.n * F)
+    n_hop_launches = len(hop_ms) // args.steps if hop_ms else 0
+    roofline = None
+    if hop_ms:
+        bytes_per_launch = bytes_recursion / n_hop_launches
+        mean_ms = float(np.mean(hop_ms))
+        achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, args.labeling))
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_hop_launch")
+        roofline = dict(bound="hbm", kernel="hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+                        algorithmic_bytes_per_launch=int(bytes_per_launch), launches_per_step=n_hop_launches,
+                        mean_launch_ms=round(mean_ms, 4), hop_ms_per_step=round(float(np.sum(hop_ms)) / args.steps, 3),
+                        project_ms_per_step=round(float(np.sum(proj_ms)) / args.steps, 3))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ref_out, cpu = cpu_baseline(op, spec, layer, x)
+        got = out[: ref_out.shape[0]].cpu().numpy()
+        err = float(np.abs(got - ref_out).max() / np.abs(ref_out).max())
+        cpu["gpu_vs_cpu_rel_err"] = err
+        assert err <= 1e-5, "GPU result differs from the CPU restatement: %g" % err
+
+    if rank == 0:
+        line = dict(metric="Cheb-TGCN fwd: G edge.timesteps/s + achieved HBM GB/s, K=5 on 160M-edge graph",
+                    value=round(value, 3), unit="G edge.timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="f32", data="synthetic",
+                    config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
+                                sharding="time steps across ranks, CSR replicated, no collective" if world > 1 else "single GPU",
+                                nnz=op.nnz, n=op.n),
+                    roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

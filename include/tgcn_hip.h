@@ -75,6 +75,16 @@ typedef struct tgcn_dense {
 const char* tgcn_last_error(void);
 int tgcn_abi_version(void);
 
+/* Optional launch timing for benchmarks: between start and stop every kernel launch made through this
+ * library is bracketed by a hipEvent pair on its own stream.  stop() synchronises those events and returns
+ * (kind, milliseconds) per launch in launch order.  Not for use under hipGraph capture. */
+#define TGCN_PROF_HOP 0
+#define TGCN_PROF_HOP_FIXUP 1
+#define TGCN_PROF_PROJECT 2
+#define TGCN_PROF_RELAYOUT 3
+int tgcn_profile_start(int32_t capacity);
+int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
+
 /* Geometry the host needs to build a schedule / size scratch for a row length C (floats).
  * `aligned16` != 0 when every operand base, row stride and batch stride is a multiple of 4 floats. */
 int tgcn_hop_vec_width(int32_t C, int aligned16);      /* floats per lane: 4 or 1 */

@@ -81,3 +81,47 @@ def test_uniform_and_pool():
     assert np.abs(g["uniform_out"]).max() <= O.uniform_bound(int(g["uniform_size"]))
     assert np.array_equal(O.gcn_pool(g["pool_x"], 2), g["pool2"])
     assert np.array_equal(O.gcn_pool(g["pool_x"], 4), g["pool4"])
+
+
+# ---------------------------------------------------------------------------- plain-C restatement (CPU baseline)
+def _c_forward(g, mode, x3, W, bias_kind, L=None):
+    from oracle import c_port
+    if L is None:
+        L = _L(g)
+    L = L.tocsr()
+    L.sort_indices()
+    b = _bias(g)
+    return c_port.forward(mode, L.indptr.astype(np.int32), L.indices.astype(np.int32), L.data.astype(np.float32), x3, W,
+                          None if b is None else b.reshape(-1), bias_kind if b is not None else 0)
+
+
+@pytest.mark.parametrize("path", golden_files("GCNCheb_") + golden_files("TGCNCheb_") + golden_files("TGCNChebH_"),
+                         ids=golden_ids(golden_files("GCNCheb_") + golden_files("TGCNCheb_") + golden_files("TGCNChebH_")))
+def test_c_port_dense_classes(path):
+    g = load_golden(path)
+    x = g["x"]
+    kind = str(g["kind"])
+    if kind == "GCNCheb" and x.ndim == 2:
+        x = x[:, :, None]
+    if kind == "TGCNCheb_H" and x.ndim == 3:
+        x = x[..., None]
+    q, n = x.shape[:2]
+    W = g["weight"].reshape(g["weight"].shape[0], -1, g["weight"].shape[-1])
+    out = _c_forward(g, 0, x.reshape(q, n, -1), W, 1 if kind == "GCNCheb" else 2)
+    assert rel_err(out, g["out"]) <= TOL
+
+
+@pytest.mark.parametrize("path", golden_files("ChebConv_") + golden_files("ChebTimeConv_"),
+                         ids=golden_ids(golden_files("ChebConv_") + golden_files("ChebTimeConv_")))
+def test_c_port_edge_classes(path):
+    g = load_golden(path)
+    x = g["x"]
+    kind = str(g["kind"])
+    if x.ndim < (3 if kind == "ChebConv" else 4):
+        x = x[..., None]
+    q, n = x.shape[:2]
+    w = g["edge_weight"] if int(g["use_weight"]) else None
+    row, col, lap = O.edge_laplacian(g["edge_index"], w, n)
+    W = g["weight"].reshape(g["weight"].shape[0], -1, g["weight"].shape[-1])
+    out = _c_forward(g, 1, x.reshape(q, n, -1), W, 1, L=O.coo_to_csr(row, col, lap, n))
+    assert rel_err(out, g["out"]) <= TOL

@@ -34,6 +34,8 @@ _P = C.c_void_p
 SIGNATURES = {
     "tgcn_last_error": (C.c_char_p, []),
     "tgcn_abi_version": (C.c_int, []),
+    "tgcn_profile_start": (C.c_int, [C.c_int32]),
+    "tgcn_profile_stop": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "tgcn_hop_vec_width": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_lanes_per_row": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_groups_per_block": (C.c_int, [C.c_int32, C.c_int]),
@@ -105,3 +107,16 @@ def stream_ptr():
 
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def profile_start(capacity=4096):
+    check(lib().tgcn_profile_start(capacity))
+
+
+def profile_stop(capacity=4096):
+    """-> list of (kind, ms) per launch, in launch order (kinds: include/tgcn_hip.h TGCN_PROF_*)."""
+    kinds = (C.c_int32 * capacity)()
+    ms = (C.c_float * capacity)()
+    n = C.c_int32(0)
+    check(lib().tgcn_profile_stop(kinds, ms, capacity, C.byref(n)))
+    return [(kinds[i], ms[i]) for i in range(n.value)]

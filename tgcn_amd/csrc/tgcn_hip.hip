@@ -12,6 +12,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "tgcn_hip.h"
 
 namespace {
@@ -31,6 +35,29 @@ thread_local char g_err[512] = "";
   } while (0)
 
 constexpr int kBlock = 256;
+
+// ---- optional launch timing (bench / tests): hipEvent pairs recorded around launches on their own stream
+struct ProfRec { hipEvent_t a, b; int kind; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+std::atomic<int> g_prof_cap{0};
+
+struct ProfScope {
+  hipEvent_t b = nullptr;
+  hipStream_t st;
+  ProfScope(int kind, hipStream_t s) : st(s) {
+    if (g_prof_cap.load(std::memory_order_relaxed) <= 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if ((int)g_prof.size() >= g_prof_cap.load()) return;
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    r.kind = kind;
+    hipEventRecord(r.a, st);
+    b = r.b;
+    g_prof.push_back(r);
+  }
+  ~ProfScope() { if (b) hipEventRecord(b, st); }
+};
 
 // --------------------------------------------------------------------------------------------------
 // hop
@@ -235,10 +262,12 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
 template <int VEC>
 int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
 #define TGCN_HOP_CASE(L)                                                                   \
-  case L:                                                                                  \
-    hipLaunchKernelGGL((hop_kernel<L, VEC>), grid, dim3(kBlock), 0, st, p);                 \
-    if (p.nlong > 0) hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); \
-    break;
+  case L: {                                                                                \
+    { ProfScope ps(TGCN_PROF_HOP, st);                                                       \
+      hipLaunchKernelGGL((hop_kernel<L, VEC>), grid, dim3(kBlock), 0, st, p); }               \
+    if (p.nlong > 0) { ProfScope ps(TGCN_PROF_HOP_FIXUP, st);                                 \
+      hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); }     \
+  } break;
   switch (lpr) {
     TGCN_HOP_CASE(1)
     TGCN_HOP_CASE(2)
@@ -455,6 +484,33 @@ extern "C" {
 const char* tgcn_last_error(void) { return g_err; }
 int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
+int tgcn_profile_start(int32_t capacity) {
+  if (capacity <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "profile: capacity %d", capacity);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof.reserve(capacity);
+  g_prof_cap.store(capacity);
+  return TGCN_OK;
+}
+
+int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_cap.store(0);
+  int n = 0;
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    hipEventSynchronize(r.b);
+    hipEventElapsedTime(&t, r.a, r.b);
+    if (n < capacity && kinds && ms) { kinds[n] = r.kind; ms[n] = t; ++n; }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  if (count) *count = n;
+  return TGCN_OK;
+}
+
 int tgcn_hop_vec_width(int32_t C, int aligned16) { return C > 0 ? hop_geom(C, aligned16).vec : 0; }
 int tgcn_hop_lanes_per_row(int32_t C, int aligned16) { return C > 0 ? hop_geom(C, aligned16).lpr : 0; }
 int tgcn_hop_groups_per_block(int32_t C, int aligned16) { return C > 0 ? kBlock / hop_geom(C, aligned16).lpr : 0; }
@@ -528,6 +584,7 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
   if (mb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
   const dim3 grid((unsigned)mb, (unsigned)((N + nt * 16 - 1) / (nt * 16)));
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(TGCN_PROF_PROJECT, st);
 #define TGCN_PROJ(NTV)                                                                               \
   if (vec4) hipLaunchKernelGGL((project_kernel<NTV, true>), grid, dim3(kBlock), 0, st, p);             \
   else hipLaunchKernelGGL((project_kernel<NTV, false>), grid, dim3(kBlock), 0, st, p);
@@ -543,6 +600,7 @@ int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int6
   const int64_t gy = (Q + kRelT - 1) / kRelT;
   if (gy > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "relayout: Q too large");
   const dim3 grid((unsigned)((n + kRelT - 1) / kRelT), (unsigned)gy);
+  ProfScope ps(TGCN_PROF_RELAYOUT, (hipStream_t)stream);
   hipLaunchKernelGGL(relayout_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, in, out, Q, n, (int)C);
   TGCN_CHECK_LAUNCH("tgcn_relayout_qnc_to_nqc_f32");
   return TGCN_OK;

@@ -85,6 +85,10 @@ class GraphOperand:
         self._sched = {}
         self._transpose = None
 
+    @property
+    def shape(self):
+        return (self.n, self.n)
+
     # ------------------------------------------------------------------ constructors
     @staticmethod
     def from_coo(n, row, col, val, device=None):
