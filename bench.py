@@ -161,6 +161,7 @@ def main():
     # ---- roofline of the dominant kernel (hop_kernel): algorithmic bytes per launch / mean launch duration
     hop_ms = [ms for kind, ms in prof if kind == 0]
     proj_ms = [ms for kind, ms in prof if kind == 2]
+    fix_ms = [ms for kind, ms in prof if kind == 1]
     C_row = H * spec["f"]
     F = q * C_row
     bytes_recursion = (K - 1) * (8 * op.nnz + 4 * (op.n + 1) + 8 * op.n * F)
@@ -178,6 +179,7 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
                         algorithmic_bytes_per_launch=int(bytes_per_launch), launches_per_step=n_hop_launches,
                         mean_launch_ms=round(mean_ms, 4), hop_ms_per_step=round(float(np.sum(hop_ms)) / args.steps, 3),
+                        fixup_ms_per_step=round(float(np.sum(fix_ms)) / args.steps, 3),
                         project_ms_per_step=round(float(np.sum(proj_ms)) / args.steps, 3))
 
     cpu = None

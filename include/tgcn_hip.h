@@ -47,22 +47,29 @@ typedef struct tgcn_csr {
   const tgcn_edge* edges; /* [nnz], rows in order */
 } tgcn_csr;
 
-/* nnz-balanced row-block schedule (built once per operand and lane-group width by the host side).
- * Rows with more than `long_thresh` stored entries are cut into segments of at most `long_thresh`
- * entries which are summed to scratch and folded by a fix-up launch (deterministic order). */
+/* Work schedule of one operand for one lane-group width (built once by the host side, tgcn_amd/graph.py).
+ *   rows with <= row_thresh stored entries: nnz-balanced row blocks, one workgroup each, one lane group per row;
+ *   longer rows: segments of bounded length, STORED IN ORDER OF THEIR FIRST COLUMN so that the groups in flight
+ *   gather from the same region of the dense operand at about the same time (hub columns then hit in L2).
+ *   A segment that is its whole row writes the row directly (seg_slot = -1); rows cut into several segments
+ *   ("long rows") sum them through numbered scratch slots that a fix-up launch folds in slot order, so results
+ *   do not depend on timing.  The first nhuge long rows (most slots) get a whole workgroup each in the fix-up. */
 typedef struct tgcn_csr_sched {
   int32_t lanes_per_row; /* lane-group width the schedule was balanced for: 1,2,4,...,64 */
-  int32_t long_thresh;
-  int32_t nblk;  /* row blocks (one workgroup each) */
-  int32_t nseg;  /* long-row segments */
-  int32_t nlong; /* long rows */
+  int32_t row_thresh;
+  int32_t nblk;     /* row blocks */
+  int32_t nseg;     /* segments */
+  int32_t nlong;    /* rows cut into more than one segment */
+  int32_t nhuge;    /* leading entries of long_row folded by a whole workgroup */
+  int32_t npartial; /* scratch slots (= segments of long rows) */
   int32_t reserved;
-  const int32_t* blk_row;  /* [nblk+1] first row of each block; blk_row[nblk] == n */
-  const int32_t* seg_row;  /* [nseg] */
-  const int32_t* seg_e0;   /* [nseg] first entry */
-  const int32_t* seg_e1;   /* [nseg] one past last entry */
-  const int32_t* long_row; /* [nlong] */
-  const int32_t* long_seg; /* [nlong+1] first segment of each long row */
+  const int32_t* blk_row;   /* [nblk+1] first row of each block; blk_row[nblk] == n */
+  const int32_t* seg_row;   /* [nseg] */
+  const int32_t* seg_e0;    /* [nseg] first entry */
+  const int32_t* seg_e1;    /* [nseg] one past last entry */
+  const int32_t* seg_slot;  /* [nseg] scratch slot, or -1: whole row, written directly */
+  const int32_t* long_row;  /* [nlong] */
+  const int32_t* long_slot; /* [nlong+1] first slot of each long row (slots of a row are consecutive, in column order) */
 } tgcn_csr_sched;
 
 /* Batched dense operand: element (b, i, c) lives at ptr[b*batch_stride + i*row_stride + c]. */
@@ -84,6 +91,9 @@ int tgcn_abi_version(void);
 #define TGCN_PROF_RELAYOUT 3
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
+
+/* Developer knob for A/B runs (tools/hop_bench.py).  key "hop_variant": 0 = shipped kernel. */
+int tgcn_set_tuning(const char* key, int32_t value);
 
 /* Geometry the host needs to build a schedule / size scratch for a row length C (floats).
  * `aligned16` != 0 when every operand base, row stride and batch stride is a multiple of 4 floats. */

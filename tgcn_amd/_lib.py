@@ -20,9 +20,10 @@ class CsrStruct(C.Structure):
 
 
 class SchedStruct(C.Structure):
-    _fields_ = [("lanes_per_row", C.c_int32), ("long_thresh", C.c_int32), ("nblk", C.c_int32), ("nseg", C.c_int32),
-                ("nlong", C.c_int32), ("reserved", C.c_int32), ("blk_row", C.c_void_p), ("seg_row", C.c_void_p),
-                ("seg_e0", C.c_void_p), ("seg_e1", C.c_void_p), ("long_row", C.c_void_p), ("long_seg", C.c_void_p)]
+    _fields_ = [("lanes_per_row", C.c_int32), ("row_thresh", C.c_int32), ("nblk", C.c_int32), ("nseg", C.c_int32),
+                ("nlong", C.c_int32), ("nhuge", C.c_int32), ("npartial", C.c_int32), ("reserved", C.c_int32),
+                ("blk_row", C.c_void_p), ("seg_row", C.c_void_p), ("seg_e0", C.c_void_p), ("seg_e1", C.c_void_p),
+                ("seg_slot", C.c_void_p), ("long_row", C.c_void_p), ("long_slot", C.c_void_p)]
 
 
 class DenseStruct(C.Structure):
@@ -36,6 +37,7 @@ SIGNATURES = {
     "tgcn_abi_version": (C.c_int, []),
     "tgcn_profile_start": (C.c_int, [C.c_int32]),
     "tgcn_profile_stop": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
+    "tgcn_set_tuning": (C.c_int, [C.c_char_p, C.c_int32]),
     "tgcn_hop_vec_width": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_lanes_per_row": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_groups_per_block": (C.c_int, [C.c_int32, C.c_int]),

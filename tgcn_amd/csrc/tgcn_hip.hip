@@ -69,8 +69,9 @@ struct HopParams {
   const int32_t* seg_row;
   const int32_t* seg_e0;
   const int32_t* seg_e1;
+  const int32_t* seg_slot;
   const int32_t* long_row;
-  const int32_t* long_seg;
+  const int32_t* long_slot;
   const float* X;
   const float* Z;
   float* Y;
@@ -78,7 +79,7 @@ struct HopParams {
   float* partial;
   int64_t x_bs, x_ld, z_bs, z_ld, y_bs, y_ld, p_bs, p_ld;
   float alpha, beta;
-  int32_t nblk, nseg, nlong, long_thresh;
+  int32_t nblk, nseg, nlong, nhuge, row_thresh;
   int32_t C, nb, nchunks, cpad;
 };
 
@@ -121,20 +122,56 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// Tuning bits of the hop kernel (NTM): which accesses carry the non-temporal hint, and ev prefetch.
+constexpr int kNtEdges = 1, kNtStores = 2, kNtGather = 4, kPrefetchEdges = 8;
+
+template <int VEC>
+__device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    __builtin_nontemporal_store(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(p));
+  } else {
+    __builtin_nontemporal_store(v[0], p);
+  }
+}
+
+template <int NTM>
+__device__ __forceinline__ void load_edge(const tgcn_edge* __restrict__ ev, int e, int& c, float& v) {
+  if constexpr (NTM & kNtEdges) {
+    using i2 = __attribute__((ext_vector_type(2))) int;
+    const i2 t = __builtin_nontemporal_load(reinterpret_cast<const i2*>(ev + e));
+    c = t.x;
+    v = __int_as_float(t.y);
+  } else {
+    const tgcn_edge t = ev[e];
+    c = t.col;
+    v = t.val;
+  }
+}
+
 // Sum of val_e * X[col_e, c0..c0+VEC) over stored entries [e0, e1), by one group of LPR lanes.
 // The group reads LPR entries with one coalesced 8-byte load per lane and hands them round with
 // in-register shuffles; gathers are issued U at a time so every lane keeps U 16-byte loads in flight.
-template <int LPR, int VEC>
+template <int LPR, int VEC, int UU, int NTM>
 __device__ __forceinline__ void accum_range(const tgcn_edge* __restrict__ ev, int e0, int e1, int t,
                                             const float* __restrict__ Xc, int64_t ldx, float (&acc)[VEC]) {
-  constexpr int U = LPR < 4 ? LPR : 4;
+  constexpr int U = LPR < UU ? LPR : UU;
+  int nx_c = 0;
+  float nx_v = 0.f;
+  if constexpr (NTM & kPrefetchEdges) {
+    if (e0 + t < e1) load_edge<NTM>(ev, e0 + t, nx_c, nx_v);
+  }
   for (int eb = e0; eb < e1; eb += LPR) {
     int my_c = 0;
     float my_v = 0.f;
-    if (eb + t < e1) {
-      const tgcn_edge e = ev[eb + t];
-      my_c = e.col;
-      my_v = e.val;
+    if constexpr (NTM & kPrefetchEdges) {
+      my_c = nx_c;
+      my_v = nx_v;
+      nx_c = 0;
+      nx_v = 0.f;
+      if (eb + LPR + t < e1) load_edge<NTM>(ev, eb + LPR + t, nx_c, nx_v);
+    } else {
+      if (eb + t < e1) load_edge<NTM>(ev, eb + t, my_c, my_v);
     }
     const int cnt = min(LPR, e1 - eb);
 #pragma unroll
@@ -147,7 +184,8 @@ __device__ __forceinline__ void accum_range(const tgcn_edge* __restrict__ ev, in
         for (int u = 0; u < U; ++u) {
           const int c = __shfl(my_c, j0 + u, LPR);
           vv[u] = __shfl(my_v, j0 + u, LPR);
-          load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
+          if constexpr (NTM & kNtGather) load_vec_nt<VEC>(Xc + (int64_t)c * ldx, xv[u]);
+          else load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
         }
       } else {  // ragged tail: clamp to the last valid entry, weight 0 (lanes past cnt hold val 0)
 #pragma unroll
@@ -155,7 +193,8 @@ __device__ __forceinline__ void accum_range(const tgcn_edge* __restrict__ ev, in
           const int j = min(j0 + u, cnt - 1);
           const int c = __shfl(my_c, j, LPR);
           vv[u] = (j0 + u < cnt) ? __shfl(my_v, j, LPR) : 0.f;
-          load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
+          if constexpr (NTM & kNtGather) load_vec_nt<VEC>(Xc + (int64_t)c * ldx, xv[u]);
+          else load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
         }
       }
 #pragma unroll
@@ -166,9 +205,12 @@ __device__ __forceinline__ void accum_range(const tgcn_edge* __restrict__ ev, in
   }
 }
 
-template <int VEC>
+template <int VEC, int NTM>
 __device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int c0, const float (&s)[VEC]) {
-  if (p.P) store_vec<VEC>(p.P + (int64_t)b * p.p_bs + (int64_t)r * p.p_ld + c0, s);
+  if (p.P) {
+    if constexpr (NTM & kNtStores) store_vec_nt<VEC>(p.P + (int64_t)b * p.p_bs + (int64_t)r * p.p_ld + c0, s);
+    else store_vec<VEC>(p.P + (int64_t)b * p.p_bs + (int64_t)r * p.p_ld + c0, s);
+  }
   float y[VEC];
   if (p.Z) {
     float z[VEC];
@@ -179,10 +221,13 @@ __device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int
 #pragma unroll
     for (int i = 0; i < VEC; ++i) y[i] = p.alpha * s[i];
   }
-  if (p.Y) store_vec<VEC>(p.Y + (int64_t)b * p.y_bs + (int64_t)r * p.y_ld + c0, y);
+  if (p.Y) {
+    if constexpr (NTM & kNtStores) store_vec_nt<VEC>(p.Y + (int64_t)b * p.y_bs + (int64_t)r * p.y_ld + c0, y);
+    else store_vec<VEC>(p.Y + (int64_t)b * p.y_bs + (int64_t)r * p.y_ld + c0, y);
+  }
 }
 
-template <int LPR, int VEC>
+template <int LPR, int VEC, int UU, int NTM>
 __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
   constexpr int GPB = kBlock / LPR;
   const int tid = threadIdx.x;
@@ -199,48 +244,85 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
     const int r0 = p.blk_row[bid], r1 = p.blk_row[bid + 1];
     for (int r = r0 + gib; r < r1; r += GPB) {
       const int e0 = p.rowptr[r], e1 = p.rowptr[r + 1];
-      if (e1 - e0 > p.long_thresh) continue;  // summed by segments below + hop_fixup_kernel
+      if (e1 - e0 > p.row_thresh) continue;  // done as column-ordered segments below
       float acc[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-      accum_range<LPR, VEC>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
-      if (cact) finish_row<VEC>(p, b, r, c0, acc);
+      accum_range<LPR, VEC, UU, NTM>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
+      if (cact) finish_row<VEC, NTM>(p, b, r, c0, acc);
     }
   } else {
+    // Segments: pieces of the longer rows, stored in order of their first column so that the groups in flight
+    // gather from the same region of the operand at about the same time (hub columns then hit in L2).
     const int s = (bid - p.nblk) * GPB + gib;
     if (s < p.nseg) {
       float acc[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-      accum_range<LPR, VEC>(p.ev, p.seg_e0[s], p.seg_e1[s], t, Xc, p.x_ld, acc);
-      store_vec<VEC>(p.partial + ((int64_t)s * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc);
+      accum_range<LPR, VEC, UU, NTM>(p.ev, p.seg_e0[s], p.seg_e1[s], t, Xc, p.x_ld, acc);
+      const int slot = p.seg_slot[s];
+      if (slot < 0) {  // the segment is its whole row
+        if (cact) finish_row<VEC, NTM>(p, b, p.seg_row[s], c0, acc);
+      } else {
+        store_vec<VEC>(p.partial + ((int64_t)slot * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc);
+      }
     }
   }
 }
 
+// Folds the partial sums of rows that were cut into several segments, in slot order (deterministic).
+// Blocks [0, nhuge): one row each, the block's groups sum interleaved slots and combine through LDS in group
+// order; the remaining blocks: one row per lane group.
 template <int LPR, int VEC>
 __global__ __launch_bounds__(kBlock) void hop_fixup_kernel(const HopParams p) {
   constexpr int GPB = kBlock / LPR;
+  constexpr int UF = 4;
+  __shared__ float red[GPB * LPR * VEC];
   const int tid = threadIdx.x;
   const int t = tid % LPR;
   const int gib = tid / LPR;
   const int chunk = blockIdx.y % p.nchunks;
   const int b = blockIdx.y / p.nchunks;
   const int c0 = (chunk * LPR + t) * VEC;
-  const int i = blockIdx.x * GPB + gib;
-  if (i >= p.nlong || c0 >= p.C) return;
-  const int row = p.long_row[i];
-  const int s0 = p.long_seg[i], s1 = p.long_seg[i + 1];
+  const bool huge = (int)blockIdx.x < p.nhuge;
+  const int i = huge ? (int)blockIdx.x : p.nhuge + ((int)blockIdx.x - p.nhuge) * GPB + gib;
+  const bool valid = i < p.nlong;
+  const int row = valid ? p.long_row[i] : 0;
+  const int s0 = valid ? p.long_slot[i] : 0, s1 = valid ? p.long_slot[i + 1] : 0;
+  const int first = huge ? s0 + gib : s0, step = huge ? GPB : 1;
+  const float* base = p.partial + (int64_t)b * p.cpad + c0;
+  const int64_t sstride = (int64_t)p.nb * p.cpad;
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-  for (int s = s0; s < s1; ++s) {
+  int s = first;
+  for (; s + (UF - 1) * step < s1; s += UF * step) {
+    float v[UF][VEC];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) load_vec_nt<VEC>(base + (int64_t)(s + u * step) * sstride, v[u]);
+#pragma unroll
+    for (int u = 0; u < UF; ++u)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += v[u][k];
+  }
+  for (; s < s1; s += step) {
     float v[VEC];
-    load_vec<VEC>(p.partial + ((int64_t)s * p.nb + b) * p.cpad + c0, v);
+    load_vec_nt<VEC>(base + (int64_t)s * sstride, v);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += v[k];
   }
-  finish_row<VEC>(p, b, row, c0, acc);
+  if (huge) {  // block-uniform branch
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[(gib * LPR + t) * VEC + k] = acc[k];
+    __syncthreads();
+    if (gib != 0) return;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int g = 0; g < GPB; ++g)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += red[(g * LPR + t) * VEC + k];
+  }
+  if (valid && c0 < p.C) finish_row<VEC, 0>(p, b, row, c0, acc);
 }
 
 struct HopGeom {
@@ -259,12 +341,33 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
   return g;
 }
 
+std::atomic<int> g_hop_variant{0};
+
+// experimental instantiations of the LPR=16 / float4 kernel (the cfg5 shape), picked with tgcn_set_tuning
+inline void launch_hop_variant(hipStream_t st, const HopParams& p, dim3 grid) {
+#define TGCN_V(U, M) hipLaunchKernelGGL((hop_kernel<16, 4, U, M>), grid, dim3(kBlock), 0, st, p); break;
+  switch (g_hop_variant.load()) {
+    case 1: TGCN_V(8, 0)
+    case 2: TGCN_V(4, kNtEdges)
+    case 3: TGCN_V(4, kNtEdges | kNtStores)
+    case 4: TGCN_V(8, kNtEdges | kNtStores)
+    case 5: TGCN_V(4, kNtEdges | kNtStores | kNtGather)
+    case 6: TGCN_V(4, kPrefetchEdges)
+    case 7: TGCN_V(8, kPrefetchEdges | kNtEdges | kNtStores)
+    case 8: TGCN_V(16, kPrefetchEdges)
+    case 9: TGCN_V(2, 0)
+    default: TGCN_V(4, 0)
+  }
+#undef TGCN_V
+}
+
 template <int VEC>
 int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
 #define TGCN_HOP_CASE(L)                                                                   \
   case L: {                                                                                \
     { ProfScope ps(TGCN_PROF_HOP, st);                                                       \
-      hipLaunchKernelGGL((hop_kernel<L, VEC>), grid, dim3(kBlock), 0, st, p); }               \
+      if (L == 16 && VEC == 4 && g_hop_variant.load() != 0) launch_hop_variant(st, p, grid);  \
+      else hipLaunchKernelGGL((hop_kernel<L, VEC, 4, 0>), grid, dim3(kBlock), 0, st, p); }    \
     if (p.nlong > 0) { ProfScope ps(TGCN_PROF_HOP_FIXUP, st);                                 \
       hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); }     \
   } break;
@@ -484,6 +587,11 @@ extern "C" {
 const char* tgcn_last_error(void) { return g_err; }
 int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
+int tgcn_set_tuning(const char* key, int32_t value) {
+  if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
+  TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
+}
+
 int tgcn_profile_start(int32_t capacity) {
   if (capacity <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "profile: capacity %d", capacity);
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -517,7 +625,7 @@ int tgcn_hop_groups_per_block(int32_t C, int aligned16) { return C > 0 ? kBlock 
 
 size_t tgcn_csr_hop_workspace_bytes(const tgcn_csr_sched* sched, int32_t nb, int32_t C, int aligned16) {
   if (!sched || C <= 0 || nb <= 0) return 0;
-  return (size_t)sched->nseg * (size_t)nb * (size_t)hop_geom(C, aligned16).cpad * sizeof(float);
+  return (size_t)sched->npartial * (size_t)nb * (size_t)hop_geom(C, aligned16).cpad * sizeof(float);
 }
 
 int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
@@ -533,29 +641,33 @@ int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, i
   const HopGeom g = hop_geom(C, al);
   if (S->lanes_per_row != g.lpr)
     TGCN_FAIL(TGCN_ERR_INVALID, "hop: schedule built for %d lanes/row, C=%d (aligned16=%d) needs %d", S->lanes_per_row, C, al, g.lpr);
-  if (S->nblk <= 0 || S->long_thresh <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: empty schedule");
+  if (S->nblk <= 0 || S->row_thresh <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: empty schedule");
+  if (S->nseg < 0 || S->nlong < 0 || S->nhuge < 0 || S->nhuge > S->nlong || S->npartial < 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: bad schedule counts");
   if ((int64_t)nb * g.nchunks > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: nb*chunks=%lld > 65535", (long long)nb * g.nchunks);
-  if (S->nseg > 0) {
-    const size_t need = (size_t)S->nseg * nb * g.cpad * sizeof(float);
+  if (S->nseg > 0 && (!S->seg_row || !S->seg_e0 || !S->seg_e1 || !S->seg_slot)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null segment arrays");
+  if (S->npartial > 0) {
+    const size_t need = (size_t)S->npartial * nb * g.cpad * sizeof(float);
     if (!workspace || workspace_bytes < need) TGCN_FAIL(TGCN_ERR_WORKSPACE, "hop: workspace %zu < %zu", workspace_bytes, need);
-    if (!S->seg_row || !S->seg_e0 || !S->seg_e1 || !S->long_row || !S->long_seg) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null segment arrays");
+    if (!S->long_row || !S->long_slot || S->nlong <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null long-row arrays");
   }
   HopParams p;
   memset(&p, 0, sizeof(p));
   p.rowptr = A->rowptr; p.ev = A->edges; p.blk_row = S->blk_row;
-  p.seg_row = S->seg_row; p.seg_e0 = S->seg_e0; p.seg_e1 = S->seg_e1; p.long_row = S->long_row; p.long_seg = S->long_seg;
+  p.seg_row = S->seg_row; p.seg_e0 = S->seg_e0; p.seg_e1 = S->seg_e1; p.seg_slot = S->seg_slot;
+  p.long_row = S->long_row; p.long_slot = S->long_slot;
   p.X = X->ptr; p.x_bs = X->batch_stride; p.x_ld = X->row_stride;
   if (Z && Z->ptr) { p.Z = Z->ptr; p.z_bs = Z->batch_stride; p.z_ld = Z->row_stride; }
   if (Y && Y->ptr) { p.Y = Y->ptr; p.y_bs = Y->batch_stride; p.y_ld = Y->row_stride; }
   if (P && P->ptr) { p.P = P->ptr; p.p_bs = P->batch_stride; p.p_ld = P->row_stride; }
   p.partial = (float*)workspace;
   p.alpha = alpha; p.beta = beta;
-  p.nblk = S->nblk; p.nseg = S->nseg; p.nlong = S->nlong; p.long_thresh = S->long_thresh;
+  p.nblk = S->nblk; p.nseg = S->nseg; p.nlong = S->nlong; p.nhuge = S->nhuge; p.row_thresh = S->row_thresh;
   p.C = C; p.nb = nb; p.nchunks = g.nchunks; p.cpad = g.cpad;
   const int gpb = kBlock / g.lpr;
   const int seg_blocks = (S->nseg + gpb - 1) / gpb;
   const dim3 grid((unsigned)(S->nblk + seg_blocks), (unsigned)(nb * g.nchunks));
-  const dim3 fix_grid((unsigned)((S->nlong + gpb - 1) / gpb > 0 ? (S->nlong + gpb - 1) / gpb : 1), (unsigned)(nb * g.nchunks));
+  const int fix_blocks = S->nhuge + (S->nlong - S->nhuge + gpb - 1) / gpb;
+  const dim3 fix_grid((unsigned)(fix_blocks > 0 ? fix_blocks : 1), (unsigned)(nb * g.nchunks));
   hipStream_t st = (hipStream_t)stream;
   return g.vec == 4 ? launch_hop_vec<4>(st, p, g.lpr, grid, fix_grid) : launch_hop_vec<1>(st, p, g.lpr, grid, fix_grid);
 }

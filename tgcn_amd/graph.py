@@ -10,7 +10,9 @@ import torch
 
 from . import _lib
 
-LONG_THRESH = 256       # stored entries one lane group sums in a row before the row is cut into segments
+ROW_THRESH = 32         # rows with more stored entries are processed as column-ordered segments
+SEG_LEN = 32            # stored entries per segment (measured on cfg5: 32 beats 16/64/128/256, tools/hop_bench.py)
+HUGE_SLOTS = 64         # long rows with more segments than this get a whole workgroup in the fix-up
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
 
@@ -20,14 +22,17 @@ def _as_i32(t):
 
 
 class Schedule:
-    """nnz-balanced row blocks for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
+    """Work schedule for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
 
-    def __init__(self, rowptr, n, lanes_per_row, long_thresh=LONG_THRESH):
+    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None):
+        row_thresh = ROW_THRESH if row_thresh is None else row_thresh
+        seg_len = max(SEG_LEN if seg_len is None else seg_len, 1)
         dev = rowptr.device
         gpb = 256 // lanes_per_row
         deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
-        is_long = deg > long_thresh
-        cost = torch.where(is_long, torch.zeros_like(deg), deg) + ROW_COST
+        is_seg = deg > row_thresh
+        # ---- short rows: nnz-balanced row blocks
+        cost = torch.where(is_seg, torch.zeros_like(deg), deg) + ROW_COST
         cum = torch.cumsum(cost, 0)
         total = int(cum[-1].item())
         target = max(gpb * 16, min(gpb * 256, -(-total // MAX_BLOCKS_HINT)))
@@ -40,29 +45,43 @@ class Schedule:
         self.blk_row = _as_i32(torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), inner,
                                           torch.full((1,), n, dtype=torch.int64, device=dev)]))
         self.nblk = nblk
-        long_rows = is_long.nonzero().flatten()
-        self.nlong = int(long_rows.numel())
-        if self.nlong:
-            nsegs = (deg[long_rows] + long_thresh - 1) // long_thresh
-            first = torch.cumsum(nsegs, 0) - nsegs
+        # ---- longer rows: segments, long rows (several segments) first by decreasing segment count
+        seg_rows = is_seg.nonzero().flatten()
+        z1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nseg = self.nlong = self.nhuge = self.npartial = 0
+        self.seg_row = self.seg_e0 = self.seg_e1 = self.seg_slot = self.long_row = z1
+        self.long_slot = torch.zeros(2, dtype=torch.int32, device=dev)
+        if seg_rows.numel():
+            nsegs = (deg[seg_rows] + seg_len - 1) // seg_len
+            order = torch.argsort(nsegs, descending=True, stable=True)
+            seg_rows, nsegs = seg_rows[order], nsegs[order]
+            self.nlong = int((nsegs > 1).sum().item())
+            self.nhuge = int((nsegs > HUGE_SLOTS).sum().item())
             self.nseg = int(nsegs.sum().item())
-            seg_row = torch.repeat_interleave(long_rows, nsegs)
+            first = torch.cumsum(nsegs, 0) - nsegs
+            row_of = torch.repeat_interleave(seg_rows, nsegs)
             within = torch.arange(self.nseg, device=dev, dtype=torch.int64) - torch.repeat_interleave(first, nsegs)
-            e0 = rowptr[seg_row].to(torch.int64) + within * long_thresh
-            e1 = torch.minimum(e0 + long_thresh, rowptr[seg_row + 1].to(torch.int64))
-            self.seg_row, self.seg_e0, self.seg_e1 = _as_i32(seg_row), _as_i32(e0), _as_i32(e1)
-            self.long_row = _as_i32(long_rows)
-            self.long_seg = _as_i32(torch.cat([first, first[-1:] + nsegs[-1:]]))
-        else:
-            self.nseg = 0
-            z = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.seg_row = self.seg_e0 = self.seg_e1 = self.long_row = z
-            self.long_seg = torch.zeros(2, dtype=torch.int32, device=dev)
+            e0 = rowptr[row_of].to(torch.int64) + within * seg_len
+            e1 = torch.minimum(e0 + seg_len, rowptr[row_of + 1].to(torch.int64))
+            # slots: segments of long rows are numbered consecutively per row (long rows come first in `seg_rows`)
+            self.npartial = int(nsegs[: self.nlong].sum().item())
+            slot = torch.arange(self.nseg, device=dev, dtype=torch.int64)
+            slot = torch.where(slot < self.npartial, slot, torch.full_like(slot, -1))
+            if self.nlong:
+                self.long_row = _as_i32(seg_rows[: self.nlong])
+                self.long_slot = _as_i32(torch.cat([first[: self.nlong], first[self.nlong - 1: self.nlong] + nsegs[self.nlong - 1: self.nlong]]))
+            # processing order: by first column
+            if edges is not None:
+                perm = torch.argsort(edges[e0, 0].to(torch.int64), stable=True)
+                row_of, e0, e1, slot = row_of[perm], e0[perm], e1[perm], slot[perm]
+            self.seg_row, self.seg_e0, self.seg_e1, self.seg_slot = _as_i32(row_of), _as_i32(e0), _as_i32(e1), _as_i32(slot)
         self.lanes_per_row = lanes_per_row
-        self.long_thresh = long_thresh
-        self.struct = _lib.SchedStruct(lanes_per_row, long_thresh, self.nblk, self.nseg, self.nlong, 0,
+        self.row_thresh = row_thresh
+        self.seg_len = seg_len
+        self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, 0,
                                        self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
-                                       self.seg_e1.data_ptr(), self.long_row.data_ptr(), self.long_seg.data_ptr())
+                                       self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
+                                       self.long_slot.data_ptr())
 
 
 class GraphOperand:
@@ -176,7 +195,7 @@ class GraphOperand:
     def schedule(self, lanes_per_row):
         s = self._sched.get(lanes_per_row)
         if s is None:
-            s = self._sched[lanes_per_row] = Schedule(self.rowptr, self.n, lanes_per_row)
+            s = self._sched[lanes_per_row] = Schedule(self.rowptr, self.n, lanes_per_row, edges=self.edges)
         return s
 
     def schedule_for(self, C_row, aligned16=True):

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""A/B micro-benchmark of hop_kernel variants on one time step of the cfg5 workload (interleaved rounds in ONE
+process, hipEvent timing on the launch stream).  Developer tool; not part of the product path.
+
+    python tools/hop_bench.py [--variants 0,1,2] [--rounds 5] [--labeling random] [--n N --nnz NNZ] [--long 256]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--labeling", default="random")
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--nnz", type=int, default=160_000_000)
+    ap.add_argument("--C", type=int, default=64)
+    ap.add_argument("--row-thresh", type=int, default=None)
+    ap.add_argument("--seg-len", type=int, default=None)
+    args = ap.parse_args()
+    from tools import synth
+    from tgcn_amd import _lib, graph, functional as F
+    if args.row_thresh:
+        graph.ROW_THRESH = args.row_thresh
+    if args.seg_len:
+        graph.SEG_LEN = args.seg_len
+    dev = torch.device("cuda:0")
+    _, row, col, val = synth.rmat(args.n, args.nnz, labeling=args.labeling, device=dev)
+    op = graph.GraphOperand.from_coo(args.n, row, col, val, dev)
+    del row, col, val
+    s = op.schedule_for(args.C)
+    print("n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d)" % (op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len), flush=True)
+    x = torch.randn(1, op.n, args.C, device=dev)
+    y = torch.empty_like(x)
+    ref = None
+    variants = [int(v) for v in args.variants.split(",")]
+    times = {v: [] for v in variants}
+    fix = {v: [] for v in variants}
+    L = _lib.lib()
+    for r in range(args.rounds + 1):
+        for v in variants:
+            _lib.check(L.tgcn_set_tuning(b"hop_variant", v))
+            _lib.profile_start(16)
+            F.csr_hop(op, x, out=y)
+            prof = _lib.profile_stop(16)
+            if r == 0:
+                if ref is None:
+                    ref = y.clone()
+                else:
+                    assert torch.equal(ref, y), "variant %d changed the result" % v
+                continue
+            times[v].append(sum(ms for k, ms in prof if k == 0))
+            fix[v].append(sum(ms for k, ms in prof if k == 1))
+    _lib.check(L.tgcn_set_tuning(b"hop_variant", 0))
+    alg = (8 * op.nnz + 4 * (op.n + 1)) / 16 + 8 * op.n * args.C
+    for v in variants:
+        t = np.array(times[v])
+        print("variant %d: median %.3f ms  min %.3f ms   -> %.0f GB/s algorithmic (cfg5 accounting); fixup %.3f ms" % (v, np.median(t), t.min(), alg / np.median(t) / 1e6, np.median(fix[v])))
+
+
+if __name__ == "__main__":
+    main()
