@@ -1,0 +1,109 @@
+"""world_size 2 / 3 gloo tests (CPU) of the N>1 paths.  The communication logic is the product code
+(tgcn_amd/dist.py); the local compute is the oracle, injected through the hooks meant for exactly this."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cheb_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _graph(n, seed, banded):
+    rng = np.random.default_rng(seed)
+    if banded:      # small cut: neighbours within +-6 plus a few long-range edges
+        row = np.repeat(np.arange(n), 5)
+        col = np.clip(row + rng.integers(-6, 7, row.shape[0]), 0, n - 1)
+        extra = rng.integers(0, n, (2, n // 20))
+        row, col = np.concatenate([row, extra[0]]), np.concatenate([col, extra[1]])
+    else:           # cut ~ everything
+        row, col = rng.integers(0, n, 8 * n), rng.integers(0, n, 8 * n)
+    row = np.concatenate([row, np.full(300, 7)])            # a hub row -> unbalanced row counts per shard
+    col = np.concatenate([col, rng.integers(0, n, 300)])
+    val = (rng.standard_normal(row.shape[0]) / 3).astype(np.float32)
+    return row, col, val
+
+
+class _ScipyOperand:
+    def __init__(self, n_rows, n_cols, row, col, val, device):
+        import scipy.sparse as sp
+        self.n, self.n_cols = n_rows, n_cols
+        self.L = sp.coo_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n_rows, n_cols)).tocsr()
+
+
+def _hop(op, x, z, alpha, beta, out):
+    y = np.stack([op.L.dot(x[b].numpy()) for b in range(x.shape[0])]).astype(np.float32)
+    y = alpha * y + (beta * z.numpy() if z is not None else 0)
+    out.copy_(torch.from_numpy(y.astype(np.float32)))
+    return out
+
+
+def _project(terms, W, bias, bias_kind, n_vertices):
+    acc = sum(t.numpy().astype(np.float64) @ W[k].numpy().astype(np.float64) for k, t in enumerate(terms))
+    if bias_kind == 1:
+        acc = acc + bias.numpy()
+    elif bias_kind == 2:
+        acc = (acc.reshape(-1, n_vertices, acc.shape[-1]) + bias.numpy()).reshape(acc.shape)
+    return torch.from_numpy(acc.astype(np.float32))
+
+
+def _worker(rank, world, port, exchange, banded, mode, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tgcn_amd.dist import VertexShardedCheb, shard_time_steps
+        n, q, C, N, K = 400, 3, 5, 4, 5
+        row, col, val = _graph(n, 1, banded)
+        rng = np.random.default_rng(2)
+        x = rng.standard_normal((q, n, C)).astype(np.float32)
+        W = (rng.standard_normal((K, C, N)) / 4).astype(np.float32)
+        bias = rng.standard_normal((n, N)).astype(np.float32)
+        sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), device="cpu",
+                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project)
+        out_local = sh.forward(torch.from_numpy(x[:, sh.lo:sh.hi]), torch.from_numpy(W),
+                               torch.from_numpy(bias[sh.lo:sh.hi]), 2, mode)
+        L = O.coo_to_csr(row, col, val, n)
+        if mode == 1:
+            basis = O.stack_chebyshev(L, x, K)
+        else:
+            P = [x]
+            for _ in range(1, K):
+                P.append(O._apply(L, P[-1]))
+            basis = np.stack(P)
+        ref = np.einsum("kqnc,kcg->qng", basis.astype(np.float64), W.astype(np.float64)) + bias
+        err = np.abs(out_local.numpy() - ref[:, sh.lo:sh.hi]).max() / np.abs(ref).max()
+        # every vertex is owned exactly once
+        owned = torch.tensor([sh.owned])
+        dist.all_reduce(owned)
+        sl = shard_time_steps(7, rank, world)
+        cnt = torch.tensor([sl.stop - sl.start])
+        dist.all_reduce(cnt)
+        ret[rank] = (float(err), sh.exchange, int(owned.item()), int(cnt.item()), sh.halo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,exchange,banded,mode", [(2, "halo", True, 1), (3, "halo", True, 0), (2, "allgather", False, 1),
+                                                        (3, "auto", False, 0), (2, "auto", True, 0)])
+def test_vertex_sharded_matches_oracle(world, exchange, banded, mode):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), exchange, banded, mode, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        err, used, owned, cnt, halo = ret[rank]
+        assert err <= 1e-5, (rank, err)
+        assert owned == 400 and cnt == 7
+        if exchange == "auto" and not banded:
+            assert used == "allgather"

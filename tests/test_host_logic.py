@@ -1,0 +1,183 @@
+"""CPU-only tests of the host side: schedule construction, weight folding, C-ABI surface, error behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_files, load_golden, rel_err
+from oracle import cheb_oracle as O
+
+
+def _rand_csr(n, m, rng, hubs=()):
+    row, col = rng.integers(0, n, m), rng.integers(0, n, m)
+    for h, d in hubs:
+        row = np.concatenate([row, np.full(d, h)])
+        col = np.concatenate([col, rng.integers(0, n, d)])
+    val = rng.standard_normal(row.shape[0]).astype(np.float32)
+    return row, col, val
+
+
+@pytest.mark.parametrize("lpr", [1, 4, 16, 64])
+def test_schedule_covers_every_entry_once(lpr):
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(lpr)
+    n = 3000
+    row, col, val = _rand_csr(n, 20000, rng, hubs=((3, 500), (77, 40), (2999, 9000)))
+    op = GraphOperand.from_coo(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val))
+    s = op.schedule(lpr)
+    rowptr = op.rowptr.numpy().astype(np.int64)
+    deg = np.diff(rowptr)
+    blk = s.blk_row.numpy()
+    assert blk[0] == 0 and blk[-1] == n and np.all(np.diff(blk) >= 0) and len(blk) == s.nblk + 1
+    covered = np.zeros(op.nnz, np.int32)
+    for r in np.nonzero(deg <= s.row_thresh)[0]:
+        covered[rowptr[r]:rowptr[r + 1]] += 1
+    seg_row, e0, e1, slot = (t.numpy() for t in (s.seg_row, s.seg_e0, s.seg_e1, s.seg_slot))
+    for i in range(s.nseg):
+        assert rowptr[seg_row[i]] <= e0[i] < e1[i] <= rowptr[seg_row[i] + 1] and e1[i] - e0[i] <= s.seg_len
+        covered[e0[i]:e1[i]] += 1
+        whole = (e0[i] == rowptr[seg_row[i]] and e1[i] == rowptr[seg_row[i] + 1])
+        assert (slot[i] < 0) == whole
+    assert np.all(covered == 1)
+    # slots of a long row are consecutive and in column (entry) order; every slot is used exactly once
+    long_row, long_slot = s.long_row.numpy(), s.long_slot.numpy()
+    assert long_slot[0] == 0 and long_slot[s.nlong] == s.npartial
+    used = np.sort(slot[slot >= 0])
+    assert np.array_equal(used, np.arange(s.npartial))
+    for i in range(s.nlong):
+        mine = np.nonzero(seg_row == long_row[i])[0]
+        mine = mine[np.argsort(e0[mine])]
+        assert np.array_equal(slot[mine], np.arange(long_slot[i], long_slot[i + 1]))
+    nslots = np.diff(long_slot[: s.nlong + 1])
+    assert np.all(nslots[: s.nhuge] > 64) and np.all(nslots[s.nhuge:] <= 64)
+    # segments are stored in order of their first column
+    first_col = op.edges[:, 0].numpy()[e0[: s.nseg]]
+    assert np.all(np.diff(first_col) >= 0)
+
+
+def test_operand_constructors_agree():
+    from tgcn_amd.graph import GraphOperand
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    n = 50
+    D = (rng.random((n, n)) < 0.1) * rng.standard_normal((n, n))
+    D = D.astype(np.float32)
+    ref = sp.csr_matrix(D)
+    for L in (torch.tensor(D), torch.tensor(D).to_sparse(), torch.tensor(D).to_sparse_csr(), ref, D):
+        op = GraphOperand.from_any(L, "cpu")
+        assert (op.to_scipy() != ref).nnz == 0
+    t = GraphOperand.from_any(ref, "cpu").transpose().to_scipy()
+    assert (t != ref.T.tocsr()).nnz == 0
+
+
+def test_edge_operand_matches_oracle():
+    from tgcn_amd.graph import GraphOperand
+    g = load_golden([f for f in golden_files("ChebConv_") if "rmat1024" in f][0])
+    n = int(g["n"])
+    op = GraphOperand.from_edge_index(torch.as_tensor(g["edge_index"]), torch.as_tensor(g["edge_weight"]), n)
+    row, col, lap = O.edge_laplacian(g["edge_index"], g["edge_weight"], n)
+    ref = O.coo_to_csr(row, col, lap, n)
+    assert abs(op.to_scipy() - ref).max() <= 1e-7
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 10, 25])
+def test_power_fold_is_the_reference_recursion(K):
+    """sum_k Xt[k] W[k] (reference_power stack) == sum_j (L^j x) W'[j] with W' = fold(W)."""
+    from tgcn_amd.functional import power_fold_matrix
+    g = load_golden([f for f in golden_files("GCNCheb_") if "dti148" in f][0])
+    L = O.csr_from_arrays(g["n"], g["rowptr"], g["col"], g["val"]).astype(np.float64)
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((2, int(g["n"]), 3))
+    W = rng.standard_normal((K, 3, 4))
+    ref = np.einsum("kqnf,kfg->qng", O.stack_reference_power(L, x, K), W)
+    c = power_fold_matrix(K, dtype=torch.float64).numpy()
+    Wf = np.einsum("kj,kfg->jfg", c, W)
+    P = [x]
+    for _ in range(1, K):
+        P.append(O._apply(L, P[-1]))
+    got = np.einsum("kqnf,kfg->qng", np.stack(P), Wf)
+    assert rel_err(got, ref) <= 1e-12
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from tgcn_amd import _lib
+    header = open(os.path.join(ROOT, "include", "tgcn_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tgcn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.lib().tgcn_abi_version() == 1
+
+
+def test_geometry_queries():
+    from tgcn_amd import _lib
+    L = _lib.lib()
+    assert (L.tgcn_hop_vec_width(64, 1), L.tgcn_hop_lanes_per_row(64, 1)) == (4, 16)
+    assert (L.tgcn_hop_vec_width(64, 0), L.tgcn_hop_lanes_per_row(64, 0)) == (1, 64)
+    assert (L.tgcn_hop_vec_width(28, 1), L.tgcn_hop_lanes_per_row(28, 1)) == (4, 8)
+    assert (L.tgcn_hop_vec_width(1, 1), L.tgcn_hop_lanes_per_row(1, 1)) == (1, 1)
+    assert L.tgcn_hop_lanes_per_row(1200, 1) == 64 and L.tgcn_hop_groups_per_block(1200, 1) == 4
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    from tgcn_amd import _lib
+    L = _lib.lib()
+    assert L.tgcn_csr_hop_f32(None, None, None, 1, 4, None, None, 1.0, 0.0, None, None, None, 0) == -1
+    assert b"null" in L.tgcn_last_error()
+    assert L.tgcn_relayout_qnc_to_nqc_f32(None, None, None, 1, 1, 1) == -1
+    assert L.tgcn_pool_max_f32(None, None, None, None, 1, 3, 1, 2) == -1
+    assert L.tgcn_set_tuning(b"nope", 1) == -1
+
+
+def test_modules_refuse_cpu_tensors():
+    import tgcn_amd
+    from tgcn_amd._lib import TgcnError
+    layer = tgcn_amd.GCNCheb(torch.eye(4), 1, 2, 2)
+    with pytest.raises(TgcnError):
+        layer(torch.randn(2, 4))
+    with pytest.raises(TgcnError):
+        tgcn_amd.gcn_pool(torch.randn(1, 4, 2))
+    conv = tgcn_amd.ChebConv(1, 2, 3)
+    with pytest.raises(TgcnError):
+        conv(torch.randn(2, 4), torch.tensor([[0, 1], [1, 0]]))
+
+
+def test_module_surface_matches_reference():
+    """Parameter names / shapes / init bound / repr, as the reference's state_dict and scripts expect
+    (tgcn/nn/gcn.py:10-31, 84-105, 160-181, 377-394, 474-491)."""
+    import tgcn_amd
+    L = torch.eye(6)
+    m = tgcn_amd.TGCNCheb(L, 3, 5, 4)
+    assert m.weight.shape == (4, 3, 5) and m.bias.shape == (1, 6, 5) and list(m.state_dict()) == ["weight", "bias"]
+    m = tgcn_amd.TGCNCheb_H(L, 1, 5, 4, 7)
+    assert m.weight.shape == (4, 7, 1, 5) and m.bias.shape == (1, 6, 5)
+    m = tgcn_amd.GCNCheb(L, 3, 5, 4, bias=False)
+    assert m.weight.shape == (4, 3, 5) and m.bias is None and list(m.state_dict()) == ["weight"]
+    assert repr(m) == "GCNCheb(3, 5, filter_order=4)"
+    m = tgcn_amd.ChebConv(3, 5, 4)
+    assert m.weight.shape == (4, 3, 5) and m.bias.shape == (5,) and repr(m) == "ChebConv(3, 5, K=4)"
+    m = tgcn_amd.ChebTimeConv(2, 5, 4, 7)
+    assert m.weight.shape == (4, 7, 2, 5) and m.bias.shape == (5,)
+    bound = 1.0 / np.sqrt(2 * 4)
+    assert m.weight.abs().max() <= bound and m.bias.abs().max() <= bound
+    g = load_golden(golden_files("uniform_pool")[0])
+    torch.manual_seed(int(g["uniform_seed"]))
+    t = torch.empty(7, 5, 3)
+    tgcn_amd.uniform(int(g["uniform_size"]), t)
+    assert np.array_equal(t.numpy(), g["uniform_out"])        # same RNG stream as the reference's uniform()
+
+
+def test_compat_import_paths():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from tgcn.nn.gcn import TGCNCheb, TGCNCheb_H, GCNCheb, ChebConv, ChebTimeConv, gcn_pool, gcn_pool_4, uniform, spmm, spmm_batch_2, spmm_batch_3;"
+            "from tgcn.nn.gcn_matmul import GCNCheb as G2; from gcn.graph import chebyshev; import tgcn_amd; assert G2 is tgcn_amd.GCNCheb"
+            % (ROOT, os.path.join(ROOT, "compat")))
+    subprocess.run([sys.executable, "-c", code], check=True)

@@ -15,38 +15,39 @@ MODE_CHEBYSHEV = 1  # edge-list classes: Tx_k = 2 L Tx_{k-1} - Tx_{k-2}  (gcn.py
 BIAS_NONE, BIAS_CHANNEL, BIAS_VERTEX_CHANNEL = 0, 1, 2
 
 
-def _dense(t, batch_stride, row_stride):
-    return _lib.DenseStruct(t.data_ptr(), int(batch_stride), int(row_stride))
+def _dense(t):
+    """(nb, rows, C) view with a contiguous last dim -> tgcn_dense (strides in floats)."""
+    assert t.dim() == 3 and t.dtype == torch.float32 and (t.shape[2] == 1 or t.stride(2) == 1), (t.shape, t.stride())
+    return _lib.DenseStruct(t.data_ptr(), int(t.stride(0)), int(t.stride(1)))
 
 
 def _aligned16(C_row, *tensors):
     ok = C_row % 4 == 0
     for t in tensors:
         if t is not None:
-            ok = ok and t.data_ptr() % 16 == 0
+            ok = ok and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0
     return ok
 
 
 # ----------------------------------------------------------------------------------------- single ops
 def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=None):
-    """One hop on a (nb, n, C) contiguous operand:  S = L x;  y = alpha*S + beta*z;  optionally also S.
-    Returns y (and S when want_p)."""
+    """One hop:  S = L x;  y = alpha*S + beta*z;  optionally also S.  x: (nb, op.n_cols, C); y, z, S: (nb, op.n, C);
+    any of them may be a strided view as long as the last dim is contiguous.  Returns y (and S when want_p)."""
     _lib.require_device(x, z)
     L = _lib.lib()
-    assert x.dim() == 3 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == op.n, (x.shape, op.n)
-    nb, n, Crow = x.shape
-    y = torch.empty_like(x) if out is None else out
-    p = (torch.empty_like(x) if p_out is None else p_out) if want_p else None
+    assert x.dim() == 3 and x.dtype == torch.float32 and x.shape[1] == op.n_cols, (x.shape, op.n_cols)
+    nb, _, Crow = x.shape
+    y = torch.empty((nb, op.n, Crow), dtype=torch.float32, device=x.device) if out is None else out
+    p = (torch.empty((nb, op.n, Crow), dtype=torch.float32, device=x.device) if p_out is None else p_out) if want_p else None
+    for t in (y, z, p):
+        assert t is None or tuple(t.shape) == (nb, op.n, Crow), (t.shape, (nb, op.n, Crow))
     al = _aligned16(Crow, x, z, y, p)
     sched = op.schedule_for(Crow, al)
     ws_bytes = L.tgcn_csr_hop_workspace_bytes(C.byref(sched.struct), nb, Crow, 1 if al else 0)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    bs = n * Crow
-    X, Y = _dense(x, bs, Crow), _dense(y, bs, Crow)
-    Z = _dense(z, bs, Crow) if z is not None else None
-    P = _dense(p, bs, Crow) if p is not None else None
-    if z is not None:
-        assert z.shape == x.shape and z.is_contiguous()
+    X, Y = _dense(x), _dense(y)
+    Z = _dense(z) if z is not None else None
+    P = _dense(p) if p is not None else None
     _lib.check(L.tgcn_csr_hop_f32(_lib.stream_ptr(), C.byref(op.struct), C.byref(sched.struct), nb, Crow, C.byref(X),
                                   C.byref(Z) if Z is not None else None, float(alpha), float(beta), C.byref(Y),
                                   C.byref(P) if P is not None else None, _lib.ptr(ws), ws.numel()))

@@ -87,9 +87,10 @@ class Schedule:
 class GraphOperand:
     """L-hat (n x n) in CSR with 8-byte packed {int32 col, float val} entries, on one device."""
 
-    def __init__(self, n, rowptr, col, val):
+    def __init__(self, n, rowptr, col, val, n_cols=None):
         assert rowptr.dtype == torch.int32 and col.dtype == torch.int32 and val.dtype == torch.float32
         self.n = int(n)
+        self.n_cols = int(n if n_cols is None else n_cols)   # > n for a vertex shard: owned rows x (owned + halo) columns
         self.nnz = int(col.numel())
         if self.nnz >= 2 ** 31 - 1 or self.n >= 2 ** 31 - 1:
             raise _lib.TgcnError("graph operand outside the int32 index range (n=%d nnz=%d)" % (self.n, self.nnz))
@@ -110,18 +111,18 @@ class GraphOperand:
 
     # ------------------------------------------------------------------ constructors
     @staticmethod
-    def from_coo(n, row, col, val, device=None):
+    def from_coo(n, row, col, val, device=None, n_cols=None):
         """Entries may come in any order; duplicates stay separate entries (their sum is what
         scatter_add computes, tgcn/nn/gcn.py:308,343)."""
         device = row.device if device is None else torch.device(device)
         row = row.to(device=device, dtype=torch.int64)
         col = col.to(device=device, dtype=torch.int64)
         val = val.to(device=device, dtype=torch.float32)
-        order = torch.argsort(row * n + col)
+        order = torch.argsort(row * (n if n_cols is None else max(n, n_cols)) + col)
         counts = torch.bincount(row, minlength=n)
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
         torch.cumsum(counts, 0, out=rowptr[1:])
-        return GraphOperand(n, _as_i32(rowptr), _as_i32(col[order]), val[order].contiguous())
+        return GraphOperand(n, _as_i32(rowptr), _as_i32(col[order]), val[order].contiguous(), n_cols)
 
     @staticmethod
     def from_dense(L, device=None):
