@@ -185,9 +185,13 @@ def test_hop_linearity_large(gpu_device):
 
 
 @pytest.mark.parametrize("M,Kc,N,T,inter", [(100, 1, 8, 5, 1), (1000, 28, 64, 5, 1), (777, 64, 64, 3, 1), (640, 15, 32, 10, 1),
-                                            (333, 7, 5, 2, 1), (1200, 12, 15, 4, 4), (64 * 9, 3, 100, 2, 9), (500, 36, 40, 33, 1)])
-def test_project_vs_numpy(M, Kc, N, T, inter, gpu_device):
-    from tgcn_amd import functional as F
+                                            (333, 7, 5, 2, 1), (1200, 12, 15, 4, 4), (64 * 9, 3, 100, 2, 9), (500, 36, 40, 33, 1),
+                                            (5000, 64, 64, 5, 1), (4100, 200, 32, 3, 1), (70, 130, 17, 2, 1)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_project_vs_numpy(M, Kc, N, T, inter, variant, gpu_device):
+    """variant 0: W-resident kernel where the weight fits in LDS; variant 1: streaming-W kernel everywhere."""
+    from tgcn_amd import functional as F, _lib
+    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", variant))
     rng = np.random.default_rng(M + Kc)
     terms = [rng.standard_normal((M, Kc)).astype(np.float32) for _ in range(T)]
     W = (rng.standard_normal((T, Kc, N)) / np.sqrt(T * Kc)).astype(np.float32)
@@ -203,6 +207,7 @@ def test_project_vs_numpy(M, Kc, N, T, inter, gpu_device):
             ref = (ref.reshape(-1, nv, N) + bias).reshape(M, N)
         out = F.cheb_project([_dev(t) for t in terms], _dev(W), None if bias is None else _dev(bias), kind, nv, inter)
         assert rel_err(out.cpu().numpy(), ref) <= TOL
+    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 0))
 
 
 def test_relayout(gpu_device):

@@ -342,6 +342,7 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
 }
 
 std::atomic<int> g_hop_variant{0};
+std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
 
 // experimental instantiations of the LPR=16 / float4 kernel (the cfg5 shape), picked with tgcn_set_tuning
 inline void launch_hop_variant(hipStream_t st, const HopParams& p, dim3 grid) {
@@ -404,7 +405,7 @@ struct ProjParams {
   const float* bias;
   float* out;
   int64_t M, ldo, n_vertices, interleave;
-  int32_t Kc, N, nterms, bias_kind, accumulate;
+  int32_t Kc, N, nterms, bias_kind, accumulate, vec_epilogue;
 };
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -512,6 +513,184 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
   }
 }
 
+// W-resident variant for the common case where the whole folded weight fits in LDS (nterms*Kc*N*4 <= 80 KB).
+// 512 threads = 8 waves; the block loads W once, then every wave streams its own 32-row tiles:
+//   global (float4, row-contiguous) -> registers -> wave-private LDS scratch [32][66] -> MFMA A fragments,
+// with the next piece's global loads issued before the current piece's MFMAs.  No block barrier in the loop.
+// W image: [term][k padded to 4][NT*16 columns], odd k rows have their 16-column halves swapped when the row
+// is a multiple of 32 floats, so the B-fragment read (k, k+1 in one 32-lane group) is conflict-free.
+constexpr int kResThreads = 512;
+constexpr int kResWaves = kResThreads / 64;
+constexpr int kResKT = 64;             // floats of K per staged piece
+constexpr int kResAS = kResKT + 2;     // scratch row stride (== 2 mod 32)
+constexpr int kResRows = 32;           // rows per wave tile (two 16-row MFMA tiles)
+constexpr int kResMaxWBytes = 80 * 1024;
+
+template <int NT>
+__device__ __forceinline__ int w_col(int k, int n) {
+  if constexpr ((NT & 1) == 0) return n ^ ((k & 1) << 4);
+  else return n;
+}
+
+template <int NT, bool VEC4>
+__global__ __launch_bounds__(kResThreads) void project_resident_kernel(const ProjParams p, const int kc4, const int64_t ntiles) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int NW = NT * 16;
+  float* Ws = smem;                                         // [nterms*kc4][NW]
+  const int ktot = p.nterms * kc4;
+  float* scratch = smem + (size_t)ktot * NW;                // [kResWaves][kResRows*kResAS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * NW;
+  // ---- W -> LDS (once)
+  for (int idx = tid; idx < ktot * NW; idx += kResThreads) {
+    const int kk = idx / NW, cc = idx % NW;
+    const int term = kk / kc4, kin = kk % kc4;
+    float v = 0.f;
+    if (kin < p.Kc && n0 + cc < p.N) v = p.W[((int64_t)term * p.Kc + kin) * p.N + n0 + cc];
+    Ws[kk * NW + w_col<NT>(kk, cc)] = v;
+  }
+  __syncthreads();
+  float* my = scratch + wave * (kResRows * kResAS);
+  const int npieces = (p.Kc + kResKT - 1) / kResKT;
+  const int total_pieces = p.nterms * npieces;
+
+  for (int64_t tile = (int64_t)blockIdx.x * kResWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kResWaves) {
+    const int64_t m0 = tile * kResRows;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float ra[VEC4 ? 8 : 32][VEC4 ? 4 : 1];
+    // loads are unconditional (clamped address, value masked afterwards): no branch per load
+    auto load_piece = [&](int pc) {
+      const int term = pc / npieces, k0 = (pc % npieces) * kResKT;
+      const float* __restrict__ A = p.a[term];
+      const int64_t lda = p.lda[term];
+      if constexpr (VEC4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int idx = lane + 64 * i, row = idx >> 4, kk = (idx & 15) * 4;
+          const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+          const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+          const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+          const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+          ra[i][0] = ok ? v.x : 0.f; ra[i][1] = ok ? v.y : 0.f; ra[i][2] = ok ? v.z : 0.f; ra[i][3] = ok ? v.w : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const bool ok = (m0 + i < p.M) && (k0 + lane < p.Kc);
+          const int64_t rr = (m0 + i < p.M) ? m0 + i : p.M - 1;
+          const int kc = (k0 + lane < p.Kc) ? k0 + lane : 0;
+          const float v = A[rr * lda + kc];
+          ra[i][0] = ok ? v : 0.f;
+        }
+      }
+    };
+    auto store_piece = [&]() {
+      if constexpr (VEC4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int idx = lane + 64 * i, row = idx >> 4, kk = (idx & 15) * 4;
+          float2* d = reinterpret_cast<float2*>(&my[row * kResAS + kk]);
+          d[0] = make_float2(ra[i][0], ra[i][1]);
+          d[1] = make_float2(ra[i][2], ra[i][3]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) my[i * kResAS + lane] = ra[i][0];
+      }
+    };
+    const float* a0 = &my[(lane & 15) * kResAS + (lane >> 4)];
+    // w_even / w_odd: this lane's row of the W image with the (lane-constant) column swizzle of even / odd
+    // column tiles folded in: (nt*16 + c) ^ sw == nt*16 + c + (nt even ? sw : -sw)
+    auto kstep = [&](int ks, const float* w_even, const float* w_odd) {
+      const float av0 = a0[ks * 4];
+      const float av1 = a0[16 * kResAS + ks * 4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = ((nt & 1) ? w_odd : w_even)[ks * 4 * NW + nt * 16];
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv, acc[1][nt], 0, 0, 0);
+      }
+    };
+
+    load_piece(0);
+    for (int pc = 0; pc < total_pieces; ++pc) {
+      store_piece();                       // previous piece's fragment reads were issued before (in-order LDS)
+      if (pc + 1 < total_pieces) load_piece(pc + 1);
+      const int term = pc / npieces, k0 = (pc % npieces) * kResKT;
+      const int ksteps = (min(kResKT, p.Kc - k0) + 3) >> 2;
+      const int kbase = term * kc4 + k0 + (lane >> 4);
+      // (kbase + 4*ks) & 1 == kbase & 1: the column swizzle is the same for every k-step of this lane
+      const int sw = ((NT & 1) == 0) ? ((kbase & 1) << 4) : 0;
+      const float* w_even = &Ws[kbase * NW + (lane & 15) + sw];
+      const float* w_odd = &Ws[kbase * NW + (lane & 15) - sw];
+      if (ksteps == kResKT / 4) {          // full piece: straight-line code so LDS reads run ahead of the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < kResKT / 4; ++ks) kstep(ks, w_even, w_odd);
+      } else {
+        for (int ks = 0; ks < ksteps; ++ks) kstep(ks, w_even, w_odd);
+      }
+    }
+    // ---- epilogue
+    if (p.vec_epilogue) {
+      // accumulators -> wave scratch (row-major) -> float4 rows: coalesced bias loads and 16-byte stores
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) my[(r * 16 + (lane >> 4) * 4 + i) * kResAS + nt * 16 + (lane & 15)] = acc[r][nt][i];
+      constexpr int SEGS = NW / 4;                        // float4 per row
+      constexpr int ITER = (kResRows * SEGS) / 64;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+        const int64_t m = m0 + row;
+        const int col = n0 + seg;
+        if (m >= p.M || col >= p.N) continue;
+        const float2 lo = *reinterpret_cast<const float2*>(&my[row * kResAS + seg]);
+        const float2 hi = *reinterpret_cast<const float2*>(&my[row * kResAS + seg + 2]);
+        float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
+        const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+        if (p.bias_kind) {
+          const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.N : 0) + col);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
+        if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+        *o = v;
+      }
+    } else {
+      const int col_l = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t m = m0 + r * 16 + (lane >> 4) * 4 + i;
+          if (m >= p.M) continue;
+          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + nt * 16 + col_l;
+            if (col >= p.N) continue;
+            float v = acc[r][nt][i];
+            if (p.bias_kind == 1) v += p.bias[col];
+            else if (p.bias_kind == 2) v += p.bias[vert * p.N + col];
+            float* o = p.out + orow * p.ldo + col;
+            if (p.accumulate) v += *o;
+            *o = v;
+          }
+        }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------------------
 // relayout (Q,n,C) -> (n,Q,C), C <= 32
 // --------------------------------------------------------------------------------------------------
@@ -589,6 +768,7 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
 int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
 }
 
@@ -691,11 +871,39 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
   }
   p.W = W; p.bias = bias; p.out = out; p.M = M; p.ldo = ldo; p.n_vertices = n_vertices; p.interleave = interleave;
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.bias_kind = bias_kind; p.accumulate = accumulate;
+  p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
   const int nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
+  hipStream_t st = (hipStream_t)stream;
+  const int kc4 = (Kc + 3) / 4 * 4;
+  const size_t wbytes = (size_t)nterms * kc4 * nt * 16 * sizeof(float);
+  const unsigned gy = (unsigned)((N + nt * 16 - 1) / (nt * 16));
+  if (wbytes <= (size_t)kResMaxWBytes && g_proj_variant.load() != 1) {
+    const size_t lds = wbytes + (size_t)kResWaves * kResRows * kResAS * sizeof(float);
+    const int64_t ntiles = (M + kResRows - 1) / kResRows;
+    int64_t gx = (ntiles + kResWaves - 1) / kResWaves;
+    if (gx > 256) gx = 256;    // one persistent workgroup per CU (LDS-limited residency)
+    const dim3 grid((unsigned)gx, gy);
+    ProfScope ps(TGCN_PROF_PROJECT, st);
+#define TGCN_PROJ_R(NTV, V4)                                                                                  \
+  {                                                                                                           \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipFuncSetAttribute((const void*)project_resident_kernel<NTV, V4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          kResMaxWBytes + kResWaves * kResRows * kResAS * (int)sizeof(float));                \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((project_resident_kernel<NTV, V4>), grid, dim3(kResThreads), lds, st, p, kc4, ntiles); \
+  }
+    if (nt == 1) { if (vec4) TGCN_PROJ_R(1, true) else TGCN_PROJ_R(1, false) }
+    else if (nt == 2) { if (vec4) TGCN_PROJ_R(2, true) else TGCN_PROJ_R(2, false) }
+    else { if (vec4) TGCN_PROJ_R(4, true) else TGCN_PROJ_R(4, false) }
+#undef TGCN_PROJ_R
+    TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (resident)");
+    return TGCN_OK;
+  }
   const int64_t mb = (M + 63) / 64;
   if (mb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
-  const dim3 grid((unsigned)mb, (unsigned)((N + nt * 16 - 1) / (nt * 16)));
-  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)mb, gy);
   ProfScope ps(TGCN_PROF_PROJECT, st);
 #define TGCN_PROJ(NTV)                                                                               \
   if (vec4) hipLaunchKernelGGL((project_kernel<NTV, true>), grid, dim3(kBlock), 0, st, p);             \
