@@ -2,7 +2,7 @@
 // See include/tgcn_hip.h for the contract and DESIGN.md for layout / roofline notes.
 //
 // Kernels
-//   hop_kernel<LPR,VEC>      row-block CSR x dense rows, fused  Y = alpha*(L X) + beta*Z  (+ P = L X)
+//   hop_kernel<LPR,VEC,U,R>  row-block CSR x dense rows, fused  Y = alpha*(L X) + beta*Z  (+ P = L X)
 //   hop_fixup_kernel<..>     folds long-row segment partials (fixed order => deterministic)
 //   project_kernel<NT,VEC4>  stacked-hop projection on v_mfma_f32_16x16x4_f32 (exact fp32)
 //   relayout_kernel          (Q,n,C) -> (n,Q,C)
@@ -123,7 +123,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // Tuning bits of the hop kernel (NTM): which accesses carry the non-temporal hint, and ev prefetch.
-constexpr int kNtEdges = 1, kNtStores = 2, kNtGather = 4, kPrefetchEdges = 8;
+constexpr int kNtEdges = 1, kNtStores = 2;
 
 template <int VEC>
 __device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[VEC]) {
@@ -149,62 +149,6 @@ __device__ __forceinline__ void load_edge(const tgcn_edge* __restrict__ ev, int 
   }
 }
 
-// Sum of val_e * X[col_e, c0..c0+VEC) over stored entries [e0, e1), by one group of LPR lanes.
-// The group reads LPR entries with one coalesced 8-byte load per lane and hands them round with
-// in-register shuffles; gathers are issued U at a time so every lane keeps U 16-byte loads in flight.
-template <int LPR, int VEC, int UU, int NTM>
-__device__ __forceinline__ void accum_range(const tgcn_edge* __restrict__ ev, int e0, int e1, int t,
-                                            const float* __restrict__ Xc, int64_t ldx, float (&acc)[VEC]) {
-  constexpr int U = LPR < UU ? LPR : UU;
-  int nx_c = 0;
-  float nx_v = 0.f;
-  if constexpr (NTM & kPrefetchEdges) {
-    if (e0 + t < e1) load_edge<NTM>(ev, e0 + t, nx_c, nx_v);
-  }
-  for (int eb = e0; eb < e1; eb += LPR) {
-    int my_c = 0;
-    float my_v = 0.f;
-    if constexpr (NTM & kPrefetchEdges) {
-      my_c = nx_c;
-      my_v = nx_v;
-      nx_c = 0;
-      nx_v = 0.f;
-      if (eb + LPR + t < e1) load_edge<NTM>(ev, eb + LPR + t, nx_c, nx_v);
-    } else {
-      if (eb + t < e1) load_edge<NTM>(ev, eb + t, my_c, my_v);
-    }
-    const int cnt = min(LPR, e1 - eb);
-#pragma unroll
-    for (int j0 = 0; j0 < LPR; j0 += U) {
-      if (j0 >= cnt) break;
-      float xv[U][VEC];
-      float vv[U];
-      if (j0 + U <= cnt) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int c = __shfl(my_c, j0 + u, LPR);
-          vv[u] = __shfl(my_v, j0 + u, LPR);
-          if constexpr (NTM & kNtGather) load_vec_nt<VEC>(Xc + (int64_t)c * ldx, xv[u]);
-          else load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
-        }
-      } else {  // ragged tail: clamp to the last valid entry, weight 0 (lanes past cnt hold val 0)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = min(j0 + u, cnt - 1);
-          const int c = __shfl(my_c, j, LPR);
-          vv[u] = (j0 + u < cnt) ? __shfl(my_v, j, LPR) : 0.f;
-          if constexpr (NTM & kNtGather) load_vec_nt<VEC>(Xc + (int64_t)c * ldx, xv[u]);
-          else load_vec<VEC>(Xc + (int64_t)c * ldx, xv[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vv[u], xv[u][i], acc[i]);
-    }
-  }
-}
-
 template <int VEC, int NTM>
 __device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int c0, const float (&s)[VEC]) {
   if (p.P) {
@@ -227,7 +171,57 @@ __device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int
   }
 }
 
-template <int LPR, int VEC, int UU, int NTM>
+// Sum of val_e * X[col_e, c0..c0+VEC) over stored entries [e0[rr], e1[rr]) of R rows (or segments) at once, by one
+// group of LPR lanes.  Per row the group reads LPR entries with one coalesced 8-byte load per lane and hands them
+// round with in-register shuffles; gathers are issued U at a time per row, so R*U 16-byte loads are in flight per
+// lane.  R > 1 keeps R independent rowptr -> entry -> gather chains going, which is what low-degree rows on wide
+// operands need (measured on the mesh config); entries are summed in stored order: deterministic.
+template <int LPR, int VEC, int UU, int R, int NTM>
+__device__ __forceinline__ void accum_multi(const tgcn_edge* __restrict__ ev, const int (&e0)[R], const int (&e1)[R], int t,
+                                            const float* __restrict__ Xc, int64_t ldx, float (&acc)[R][VEC]) {
+  constexpr int U = LPR < UU ? LPR : UU;
+  int len_max = 0;
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) len_max = max(len_max, e1[rr] - e0[rr]);
+  for (int off = 0; off < len_max; off += LPR) {
+    int my_c[R], cnt[R];
+    float my_v[R];
+    int cmax = 0;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      my_c[rr] = 0;
+      my_v[rr] = 0.f;
+      const int e = e0[rr] + off + t;
+      if (e < e1[rr]) load_edge<NTM>(ev, e, my_c[rr], my_v[rr]);
+      cnt[rr] = min(LPR, max(0, e1[rr] - e0[rr] - off));
+      cmax = max(cmax, cnt[rr]);
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < LPR; j0 += U) {
+      if (j0 >= cmax) break;
+      float xv[R][U][VEC];
+      float vv[R][U];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = __shfl(my_c[rr], j0 + u, LPR);
+          vv[rr][u] = __shfl(my_v[rr], j0 + u, LPR);   // 0 past the end of the row
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) xv[rr][u][i] = 0.f;
+          if (j0 + u < cnt[rr]) load_vec<VEC>(Xc + (int64_t)c * ldx, xv[rr][u]);
+        }
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[rr][i] = fmaf(vv[rr][u], xv[rr][u][i], acc[rr][i]);
+    }
+  }
+}
+
+template <int LPR, int VEC, int UU, int R, int NTM>
 __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
   constexpr int GPB = kBlock / LPR;
   const int tid = threadIdx.x;
@@ -242,29 +236,47 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
   if (bid < p.nblk) {
     bid = xcd_remap(bid, p.nblk);
     const int r0 = p.blk_row[bid], r1 = p.blk_row[bid + 1];
-    for (int r = r0 + gib; r < r1; r += GPB) {
-      const int e0 = p.rowptr[r], e1 = p.rowptr[r + 1];
-      if (e1 - e0 > p.row_thresh) continue;  // done as column-ordered segments below
-      float acc[VEC];
+    for (int rb = r0 + gib; rb < r1; rb += GPB * R) {
+      int e0[R], e1[R];
+      bool live[R];
+      float acc[R][VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-      accum_range<LPR, VEC, UU, NTM>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
-      if (cact) finish_row<VEC, NTM>(p, b, r, c0, acc);
+      for (int rr = 0; rr < R; ++rr) {
+        const int r = rb + rr * GPB;
+        e0[rr] = e1[rr] = 0;
+        if (r < r1) { e0[rr] = p.rowptr[r]; e1[rr] = p.rowptr[r + 1]; }
+        live[rr] = (r < r1) && (e1[rr] - e0[rr] <= p.row_thresh);
+        if (!live[rr]) e1[rr] = e0[rr];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[rr][i] = 0.f;
+      }
+      accum_multi<LPR, VEC, UU, R, NTM>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+        if (live[rr] && cact) finish_row<VEC, NTM>(p, b, rb + rr * GPB, c0, acc[rr]);
     }
   } else {
-    // Segments: pieces of the longer rows, stored in order of their first column so that the groups in flight
-    // gather from the same region of the operand at about the same time (hub columns then hit in L2).
-    const int s = (bid - p.nblk) * GPB + gib;
-    if (s < p.nseg) {
-      float acc[VEC];
+    const int sb = (bid - p.nblk) * GPB * R + gib;
+    int e0[R], e1[R];
+    float acc[R][VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-      accum_range<LPR, VEC, UU, NTM>(p.ev, p.seg_e0[s], p.seg_e1[s], t, Xc, p.x_ld, acc);
+    for (int rr = 0; rr < R; ++rr) {
+      const int s = sb + rr * GPB;
+      e0[rr] = e1[rr] = 0;
+      if (s < p.nseg) { e0[rr] = p.seg_e0[s]; e1[rr] = p.seg_e1[s]; }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[rr][i] = 0.f;
+    }
+    accum_multi<LPR, VEC, UU, R, NTM>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const int s = sb + rr * GPB;
+      if (s >= p.nseg) continue;
       const int slot = p.seg_slot[s];
-      if (slot < 0) {  // the segment is its whole row
-        if (cact) finish_row<VEC, NTM>(p, b, p.seg_row[s], c0, acc);
+      if (slot < 0) {
+        if (cact) finish_row<VEC, NTM>(p, b, p.seg_row[s], c0, acc[rr]);
       } else {
-        store_vec<VEC>(p.partial + ((int64_t)slot * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc);
+        store_vec<VEC>(p.partial + ((int64_t)slot * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc[rr]);
       }
     }
   }
@@ -344,33 +356,52 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
 std::atomic<int> g_hop_variant{0};
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
 
-// experimental instantiations of the LPR=16 / float4 kernel (the cfg5 shape), picked with tgcn_set_tuning
-inline void launch_hop_variant(hipStream_t st, const HopParams& p, dim3 grid) {
-#define TGCN_V(U, M) hipLaunchKernelGGL((hop_kernel<16, 4, U, M>), grid, dim3(kBlock), 0, st, p); break;
-  switch (g_hop_variant.load()) {
-    case 1: TGCN_V(8, 0)
-    case 2: TGCN_V(4, kNtEdges)
-    case 3: TGCN_V(4, kNtEdges | kNtStores)
-    case 4: TGCN_V(8, kNtEdges | kNtStores)
-    case 5: TGCN_V(4, kNtEdges | kNtStores | kNtGather)
-    case 6: TGCN_V(4, kPrefetchEdges)
-    case 7: TGCN_V(8, kPrefetchEdges | kNtEdges | kNtStores)
-    case 8: TGCN_V(16, kPrefetchEdges)
-    case 9: TGCN_V(2, 0)
-    default: TGCN_V(4, 0)
-  }
-#undef TGCN_V
+template <int LPR, int VEC, int U, int R>
+inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
+  constexpr int GPB = kBlock / LPR;
+  grid.x = (unsigned)(p.nblk + (p.nseg + GPB * R - 1) / (GPB * R));
+  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, 0>), grid, dim3(kBlock), 0, st, p);
 }
+
+// developer variants of the two float4 shapes that matter for the benchmarks (tools/hop_bench.py)
+inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3 grid) {
+  const int v = g_hop_variant.load();
+  if (lpr == 16) {
+    switch (v) {
+      case 1: launch_hop<16, 4, 8, 1>(st, p, grid); return true;
+      case 2: launch_hop<16, 4, 4, 2>(st, p, grid); return true;
+      case 3: launch_hop<16, 4, 2, 1>(st, p, grid); return true;
+      default: return false;
+    }
+  }
+  if (lpr == 64) {
+    switch (v) {
+      case 1: launch_hop<64, 4, 4, 1>(st, p, grid); return true;
+      case 2: launch_hop<64, 4, 4, 2>(st, p, grid); return true;
+      case 3: launch_hop<64, 4, 8, 2>(st, p, grid); return true;
+      case 4: launch_hop<64, 4, 8, 1>(st, p, grid); return true;
+      default: return false;
+    }
+  }
+  return false;
+}
+
+// rows interleaved per lane group: wide operands (a whole wave per row chunk) run 4 rows at once
+template <int L> struct HopRows { static constexpr int value = (L == 64) ? 4 : 1; };
 
 template <int VEC>
 int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
-#define TGCN_HOP_CASE(L)                                                                   \
-  case L: {                                                                                \
-    { ProfScope ps(TGCN_PROF_HOP, st);                                                       \
-      if (L == 16 && VEC == 4 && g_hop_variant.load() != 0) launch_hop_variant(st, p, grid);  \
-      else hipLaunchKernelGGL((hop_kernel<L, VEC, 4, 0>), grid, dim3(kBlock), 0, st, p); }    \
-    if (p.nlong > 0) { ProfScope ps(TGCN_PROF_HOP_FIXUP, st);                                 \
-      hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); }     \
+#define TGCN_HOP_CASE(L)                                                                    \
+  case L: {                                                                                 \
+    { ProfScope ps(TGCN_PROF_HOP, st);                                                      \
+      if (!(VEC == 4 && g_hop_variant.load() != 0 && launch_hop_variant(L, st, p, grid))) { \
+        /* interleave rows only when the grid still fills the chip afterwards */            \
+        if (HopRows<L>::value > 1 && (int64_t)p.nblk * grid.y >= 4096)                       \
+          launch_hop<L, VEC, 4, HopRows<L>::value>(st, p, grid);                            \
+        else launch_hop<L, VEC, 4, 1>(st, p, grid);                                         \
+      } }                                                                                   \
+    if (p.nlong > 0) { ProfScope ps(TGCN_PROF_HOP_FIXUP, st);                               \
+      hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); }   \
   } break;
   switch (lpr) {
     TGCN_HOP_CASE(1)

@@ -130,7 +130,18 @@ def cheb_stack(op, x3, K, mode):
     return st
 
 
+_fold_cache = {}
+
+
 def power_fold_matrix(K, device=None, dtype=torch.float32):
+    key = (K, str(device), dtype)
+    c = _fold_cache.get(key)
+    if c is None:
+        c = _fold_cache[key] = _power_fold_matrix(K, device, dtype)
+    return c
+
+
+def _power_fold_matrix(K, device=None, dtype=torch.float32):
     """c[k, j] with Xt[k] = sum_j c[k, j] L^j x for the reference_power recursion: c[0]=e0, c[1]=e1,
     c[k] = 2 e_k - c[k-2].  Folding it into the weight (W'_j = sum_k c[k,j] W_k) turns the layer into one
     monomial chain: no subtrahend reads, no second output (verified there to <= 6.3e-7)."""

@@ -15,14 +15,16 @@ import torch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9")
+    ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--labeling", default="random")
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--nnz", type=int, default=160_000_000)
     ap.add_argument("--C", type=int, default=64)
+    ap.add_argument("--graph", default="rmat")
     ap.add_argument("--row-thresh", type=int, default=None)
     ap.add_argument("--seg-len", type=int, default=None)
+    ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
     args = ap.parse_args()
     from tools import synth
     from tgcn_amd import _lib, graph, functional as F
@@ -31,10 +33,13 @@ def main():
     if args.seg_len:
         graph.SEG_LEN = args.seg_len
     dev = torch.device("cuda:0")
-    _, row, col, val = synth.rmat(args.n, args.nnz, labeling=args.labeling, device=dev)
+    if args.graph == "mesh":
+        args.n, row, col, val = synth.sheet_mesh(300, device=dev)
+    else:
+        _, row, col, val = synth.rmat(args.n, args.nnz, labeling=args.labeling, device=dev)
     op = graph.GraphOperand.from_coo(args.n, row, col, val, dev)
     del row, col, val
-    s = op.schedule_for(args.C)
+    s = op.schedule_for(args.C // args.split)
     print("n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d)" % (op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len), flush=True)
     x = torch.randn(1, op.n, args.C, device=dev)
     y = torch.empty_like(x)
@@ -47,7 +52,9 @@ def main():
         for v in variants:
             _lib.check(L.tgcn_set_tuning(b"hop_variant", v))
             _lib.profile_start(16)
-            F.csr_hop(op, x, out=y)
+            cs = args.C // args.split
+            for sp in range(args.split):
+                F.csr_hop(op, x[:, :, sp * cs:(sp + 1) * cs], out=y[:, :, sp * cs:(sp + 1) * cs])
             prof = _lib.profile_stop(16)
             if r == 0:
                 if ref is None:
@@ -58,7 +65,7 @@ def main():
             times[v].append(sum(ms for k, ms in prof if k == 0))
             fix[v].append(sum(ms for k, ms in prof if k == 1))
     _lib.check(L.tgcn_set_tuning(b"hop_variant", 0))
-    alg = (8 * op.nnz + 4 * (op.n + 1)) / 16 + 8 * op.n * args.C
+    alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph == 'rmat' else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
         print("variant %d: median %.3f ms  min %.3f ms   -> %.0f GB/s algorithmic (cfg5 accounting); fixup %.3f ms" % (v, np.median(t), t.min(), alg / np.median(t) / 1e6, np.median(fix[v])))
