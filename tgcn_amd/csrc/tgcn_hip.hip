@@ -355,6 +355,27 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
 
 std::atomic<int> g_hop_variant{0};
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
+std::atomic<int> g_overlap{0};        // layer driver: projection of pass i on a side stream under the hops of pass i+1
+
+struct SideStream { hipStream_t st = nullptr; hipEvent_t hops_done[2] = {nullptr, nullptr}; hipEvent_t proj_done[2] = {nullptr, nullptr}; };
+std::mutex g_side_mu;
+SideStream g_side[16];
+
+// One helper stream + 4 events per device, created on first use and kept for the life of the process.
+SideStream* side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream& s = g_side[dev];
+  if (!s.st) {
+    if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { s.st = nullptr; return nullptr; }
+    for (int i = 0; i < 2; ++i) {
+      hipEventCreateWithFlags(&s.hops_done[i], hipEventDisableTiming);
+      hipEventCreateWithFlags(&s.proj_done[i], hipEventDisableTiming);
+    }
+  }
+  return &s;
+}
 
 template <int LPR, int VEC, int U, int R>
 inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
@@ -800,6 +821,7 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "overlap") == 0) { g_overlap.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
 }
 
@@ -961,6 +983,12 @@ int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int6
 //   [xt]        n*q*C floats           (layout 1 only: re-laid input)
 //   [hop 1..K-1] (K-1) * qc*n*C floats
 //   [partial]   long-row segment scratch for one hop
+static int fwd_nsets(int64_t q, int64_t qc, int32_t layout) {
+  // two sets of hop tensors when there are several passes: the projection of pass i (side stream, MFMA-bound)
+  // overlaps the hops of pass i+1 (memory-bound)
+  return (layout == 0 && q > qc && g_overlap.load() != 0) ? 2 : 1;
+}
+
 static void fwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t C, int32_t layout,
                           int64_t qc, size_t* off_xt, size_t* off_hops, size_t* hop_bytes, size_t* off_part, size_t* total) {
   size_t o = 0;
@@ -968,7 +996,7 @@ static void fwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t
   if (layout == 1) o += align_up((size_t)q * n * C * sizeof(float), 256);
   *off_hops = o;
   *hop_bytes = align_up((size_t)qc * n * C * sizeof(float), 256);
-  o += (size_t)(K > 1 ? K - 1 : 0) * *hop_bytes;
+  o += (size_t)fwd_nsets(q, qc, layout) * (size_t)(K > 1 ? K - 1 : 0) * *hop_bytes;
   *off_part = o;
   const int32_t nb = layout == 1 ? 1 : (int32_t)qc;
   const int32_t Crow = layout == 1 ? (int32_t)(q * C) : C;
@@ -1006,8 +1034,14 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
   int64_t ldas[kMaxTerms];
   int rc;
 
-  for (int64_t q0 = 0; q0 < q; q0 += qc) {
+  const int nsets = fwd_nsets(q, qc, layout);
+  SideStream* side = nsets == 2 ? side_stream() : nullptr;
+  hipStream_t main_st = (hipStream_t)stream;
+  const size_t set_bytes = (size_t)(K > 1 ? K - 1 : 0) * hop_bytes;
+  int pass = 0;
+  for (int64_t q0 = 0; q0 < q; q0 += qc, ++pass) {
     const int64_t qn = (q - q0 < qc) ? (q - q0) : qc;
+    const int set = side ? (pass & 1) : 0;
     // operand view of this pass
     int32_t nb, Crow;
     const float* x0;
@@ -1019,7 +1053,11 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
       x0 = x + q0 * n * C; nb = (int32_t)qn; Crow = C;
     }
     const int64_t bs = (int64_t)n * Crow;
-    auto hop_ptr = [&](int k) -> float* { return k == 0 ? const_cast<float*>(x0) : (float*)(ws + off_hops + (size_t)(k - 1) * hop_bytes); };
+    auto hop_ptr = [&](int k) -> float* {
+      return k == 0 ? const_cast<float*>(x0) : (float*)(ws + off_hops + (size_t)set * set_bytes + (size_t)(k - 1) * hop_bytes);
+    };
+    // this set was last read by the projection of pass-2: wait for it before overwriting
+    if (side && pass >= 2 && hipStreamWaitEvent(main_st, side->proj_done[set], 0) != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "forward: stream wait failed");
     for (int k = 1; k < K; ++k) {
       tgcn_dense X = {hop_ptr(k - 1), bs, Crow};
       tgcn_dense Y = {hop_ptr(k), bs, Crow};
@@ -1031,6 +1069,12 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
       }
       if (rc != TGCN_OK) return rc;
     }
+    void* proj_stream = stream;
+    if (side) {
+      if (hipEventRecord(side->hops_done[set], main_st) != hipSuccess || hipStreamWaitEvent(side->st, side->hops_done[set], 0) != hipSuccess)
+        TGCN_FAIL(TGCN_ERR_LAUNCH, "forward: stream fork failed");
+      proj_stream = side->st;
+    }
     // projection, in chunks of <= 32 terms
     const int64_t M = (layout == 1) ? n * q : qn * n;
     float* o0 = (layout == 1) ? out : out + q0 * n * N;
@@ -1038,10 +1082,15 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
       const int nt = (K - k0 < kMaxTerms) ? K - k0 : kMaxTerms;
       for (int t = 0; t < nt; ++t) { terms[t] = hop_ptr(k0 + t); ldas[t] = C; }
       const bool last = (k0 + nt >= K);
-      rc = tgcn_cheb_project_f32(stream, M, C, N, nt, terms, ldas, W + (size_t)k0 * C * N, last ? bias : nullptr,
+      rc = tgcn_cheb_project_f32(proj_stream, M, C, N, nt, terms, ldas, W + (size_t)k0 * C * N, last ? bias : nullptr,
                                  last ? bias_kind : 0, n, layout == 1 ? q : 1, k0 > 0 ? 1 : 0, o0, N);
       if (rc != TGCN_OK) return rc;
     }
+    if (side && hipEventRecord(side->proj_done[set], side->st) != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "forward: event record failed");
+  }
+  if (side) {  // join: everything the side stream did is ordered before whatever the caller enqueues next
+    for (int i = 0; i < 2 && i < pass; ++i)
+      if (hipStreamWaitEvent(main_st, side->proj_done[i], 0) != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "forward: stream join failed");
   }
   return TGCN_OK;
 }

@@ -12,6 +12,7 @@ from . import _lib
 
 ROW_THRESH = 32         # rows with more stored entries are processed as column-ordered segments
 SEG_LEN = 32            # stored entries per segment (measured on cfg5: 32 beats 16/64/128/256, tools/hop_bench.py)
+SEG_KEY = "first"       # column of the segment used as its place in the processing order
 HUGE_SLOTS = 64         # long rows with more segments than this get a whole workgroup in the fix-up
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
@@ -72,7 +73,15 @@ class Schedule:
                 self.long_slot = _as_i32(torch.cat([first[: self.nlong], first[self.nlong - 1: self.nlong] + nsegs[self.nlong - 1: self.nlong]]))
             # processing order: by first column
             if edges is not None:
-                perm = torch.argsort(edges[e0, 0].to(torch.int64), stable=True)
+                if SEG_KEY == "middle":
+                    key = edges[(e0 + e1) // 2, 0].to(torch.int64)
+                elif SEG_KEY == "last":
+                    key = edges[e1 - 1, 0].to(torch.int64)
+                elif SEG_KEY == "first_then_last":
+                    key = edges[e0, 0].to(torch.int64) * (n + 1) + edges[e1 - 1, 0].to(torch.int64)
+                else:
+                    key = edges[e0, 0].to(torch.int64)
+                perm = torch.argsort(key, stable=True)
                 row_of, e0, e1, slot = row_of[perm], e0[perm], e1[perm], slot[perm]
             self.seg_row, self.seg_e0, self.seg_e1, self.seg_slot = _as_i32(row_of), _as_i32(e0), _as_i32(e1), _as_i32(slot)
         self.lanes_per_row = lanes_per_row

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--graph", default="rmat")
     ap.add_argument("--row-thresh", type=int, default=None)
     ap.add_argument("--seg-len", type=int, default=None)
+    ap.add_argument("--seg-key", default="first")
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
     args = ap.parse_args()
     from tools import synth
@@ -32,6 +33,7 @@ def main():
         graph.ROW_THRESH = args.row_thresh
     if args.seg_len:
         graph.SEG_LEN = args.seg_len
+    graph.SEG_KEY = args.seg_key
     dev = torch.device("cuda:0")
     if args.graph == "mesh":
         args.n, row, col, val = synth.sheet_mesh(300, device=dev)
