@@ -121,6 +121,14 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
                           const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                           int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo);
 
+/* Weight gradient of the projection (backward of gcn.py:39,113,194 w.r.t. weight):
+ *   dW[t*Kc + c, n] = sum_m A_t[m, c] * G[m, n]
+ * A_t as in tgcn_cheb_project_f32 (host arrays of nterms <= 32 pointers / strides), G: M x N with row stride ldg,
+ * dW: (nterms*Kc) x N contiguous.  fp32 MFMA, two-stage reduction in fixed order (deterministic). */
+size_t tgcn_cheb_wgrad_workspace_bytes(int64_t M, int32_t Kc, int32_t N, int32_t nterms);
+int tgcn_cheb_wgrad_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
+                        const int64_t* lda, const float* G, int64_t ldg, float* dW, void* workspace, size_t workspace_bytes);
+
 /* (Q, n, C) -> (n, Q, C) re-layout so that short per-sample rows become one long row per vertex. */
 int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int64_t Q, int64_t n, int32_t C);
 

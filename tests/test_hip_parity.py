@@ -210,6 +210,19 @@ def test_project_vs_numpy(M, Kc, N, T, inter, variant, gpu_device):
     _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 0))
 
 
+@pytest.mark.parametrize("M,Kc,N,T", [(1000, 64, 64, 5), (5003, 28, 64, 3), (333, 7, 5, 2), (4096, 100, 70, 2), (50, 1, 8, 6), (9000, 12, 15, 33)])
+def test_wgrad_vs_numpy(M, Kc, N, T, gpu_device):
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(M + Kc)
+    terms = [rng.standard_normal((M, Kc)).astype(np.float32) for _ in range(T)]
+    g = rng.standard_normal((M, N)).astype(np.float32)
+    ref = np.stack([t.astype(np.float64).T @ g.astype(np.float64) for t in terms])
+    dW = F.cheb_wgrad([_dev(t) for t in terms], _dev(g))
+    assert rel_err(dW.cpu().numpy(), ref) <= TOL
+    dW2 = F.cheb_wgrad([_dev(t) for t in terms], _dev(g))
+    assert torch.equal(dW, dW2)          # fixed reduction order
+
+
 def test_relayout(gpu_device):
     import ctypes as C
     from tgcn_amd import _lib

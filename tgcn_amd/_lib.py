@@ -48,6 +48,9 @@ SIGNATURES = {
     "tgcn_cheb_project_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P),
                                         C.POINTER(C.c_int64), _P, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                         _P, C.c_int64]),
+    "tgcn_cheb_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "tgcn_cheb_wgrad_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64), _P,
+                                      C.c_int64, _P, _P, C.c_size_t]),
     "tgcn_relayout_qnc_to_nqc_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int32]),
     "tgcn_cheb_forward_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64,
                                                        C.c_int32, C.c_int32, C.c_int64]),

@@ -744,6 +744,82 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
 }
 
 // --------------------------------------------------------------------------------------------------
+// weight gradient: dW[t][c][n] = sum_m A_t[m][c] * G[m][n]   (backward of the projection; fp32 MFMA)
+// --------------------------------------------------------------------------------------------------
+// Stage 1: block b sums rows [b*rows_per_block, ...) into partial[b]; wave w owns the 16-wide c tiles w, w+4, ...
+// and, per tile, TG terms x all n tiles (<= 4) as MFMA accumulators (A^T and G fragments are read straight from
+// global: lane (r, kq) reads row m0+kq, column c0+r).  Stage 2 folds the partials in block order: deterministic.
+struct WgradParams {
+  const float* a[kMaxTerms];
+  int64_t lda[kMaxTerms];
+  const float* G;
+  float* partial;   // [nblocks][nterms*Kc][N]
+  float* dW;        // [nterms*Kc][N]
+  int64_t M, ldg, rows_per_block;
+  int32_t Kc, N, nterms, nblocks;
+};
+
+constexpr int kWgTerms = 5;   // terms accumulated at once per wave (register budget: 5 * 4 tiles * 4 regs)
+
+__global__ __launch_bounds__(kBlock) void wgrad_partial_kernel(const WgradParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t m_lo = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t m_hi = min(p.M, m_lo + p.rows_per_block);
+  const int n0 = blockIdx.y * 64;
+  const int ctiles = (p.Kc + 15) / 16;
+  float* part = p.partial + (size_t)blockIdx.x * p.nterms * p.Kc * p.N;
+  for (int ct = wave; ct < ctiles; ct += 4) {
+    const int c = ct * 16 + r;
+    for (int t0 = 0; t0 < p.nterms; t0 += kWgTerms) {
+      f32x4 acc[kWgTerms][4];
+#pragma unroll
+      for (int t = 0; t < kWgTerms; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int64_t m0 = m_lo; m0 < m_hi; m0 += 4) {
+        const int64_t m = m0 + kq;
+        const bool mok = m < m_hi;
+        float gv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + j * 16 + r;
+          gv[j] = (mok && n < p.N) ? p.G[m * p.ldg + n] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < kWgTerms; ++t) {
+          if (t0 + t >= p.nterms) break;
+          const float av = (mok && c < p.Kc) ? p.a[t0 + t][m * p.lda[t0 + t] + c] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gv[j], acc[t][j], 0, 0, 0);
+        }
+      }
+      // D layout: col = lane&15 (n within tile), row = (lane>>4)*4 + i (c within tile)
+#pragma unroll
+      for (int t = 0; t < kWgTerms; ++t) {
+        if (t0 + t >= p.nterms) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int cc = ct * 16 + kq * 4 + i, n = n0 + j * 16 + r;
+            if (cc < p.Kc && n < p.N) part[((size_t)(t0 + t) * p.Kc + cc) * p.N + n] = acc[t][j][i];
+          }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const WgradParams p) {
+  const int64_t total = (int64_t)p.nterms * p.Kc * p.N;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    float s = 0.f;
+    for (int b = 0; b < p.nblocks; ++b) s += p.partial[(size_t)b * total + e];
+    p.dW[e] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // relayout (Q,n,C) -> (n,Q,C), C <= 32
 // --------------------------------------------------------------------------------------------------
 constexpr int kRelT = 16;
@@ -964,6 +1040,41 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
   if (nt == 1) { TGCN_PROJ(1) } else if (nt == 2) { TGCN_PROJ(2) } else { TGCN_PROJ(4) }
 #undef TGCN_PROJ
   TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32");
+  return TGCN_OK;
+}
+
+static int wgrad_blocks(int64_t M) {
+  int64_t b = (M + 1023) / 1024;   // >= 1024 rows per block
+  if (b > 1024) b = 1024;
+  return (int)(b < 1 ? 1 : b);
+}
+
+size_t tgcn_cheb_wgrad_workspace_bytes(int64_t M, int32_t Kc, int32_t N, int32_t nterms) {
+  if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0) return 0;
+  return (size_t)wgrad_blocks(M) * nterms * Kc * N * sizeof(float);
+}
+
+int tgcn_cheb_wgrad_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
+                        const int64_t* lda, const float* G, int64_t ldg, float* dW, void* workspace, size_t workspace_bytes) {
+  if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !G || !dW) TGCN_FAIL(TGCN_ERR_INVALID, "wgrad: bad argument");
+  if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "wgrad: nterms %d > %d", nterms, kMaxTerms);
+  const size_t need = tgcn_cheb_wgrad_workspace_bytes(M, Kc, N, nterms);
+  if (!workspace || workspace_bytes < need) TGCN_FAIL(TGCN_ERR_WORKSPACE, "wgrad: workspace %zu < %zu", workspace_bytes, need);
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  for (int t = 0; t < nterms; ++t) {
+    if (!a[t]) TGCN_FAIL(TGCN_ERR_INVALID, "wgrad: null term %d", t);
+    p.a[t] = a[t];
+    p.lda[t] = lda[t];
+  }
+  p.G = G; p.partial = (float*)workspace; p.dW = dW; p.M = M; p.ldg = ldg;
+  p.Kc = Kc; p.N = N; p.nterms = nterms; p.nblocks = wgrad_blocks(M);
+  p.rows_per_block = ((M + p.nblocks - 1) / p.nblocks + 3) / 4 * 4;
+  p.nblocks = (int)((M + p.rows_per_block - 1) / p.rows_per_block);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(p.nblocks, (N + 63) / 64), dim3(kBlock), 0, st, p);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_1d((int64_t)nterms * Kc * N)), dim3(kBlock), 0, st, p);
+  TGCN_CHECK_LAUNCH("tgcn_cheb_wgrad_f32");
   return TGCN_OK;
 }
 

@@ -77,6 +77,25 @@ def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
     return out
 
 
+def cheb_wgrad(terms, g2d):
+    """dW[t] = terms[t]^T @ g2d  ->  (T, Kc, N); terms: list of (M, Kc) views with contiguous rows, g2d: (M, N)."""
+    _lib.require_device(g2d, *terms)
+    L = _lib.lib()
+    T = len(terms)
+    M, Kc = terms[0].shape
+    N = g2d.shape[1]
+    dW = torch.empty((T, Kc, N), dtype=torch.float32, device=g2d.device)
+    for t0 in range(0, T, 32):
+        nt = min(32, T - t0)
+        ws_bytes = L.tgcn_cheb_wgrad_workspace_bytes(M, Kc, N, nt)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g2d.device)
+        a = (C.c_void_p * nt)(*[terms[t0 + i].data_ptr() for i in range(nt)])
+        lda = (C.c_int64 * nt)(*[terms[t0 + i].stride(0) for i in range(nt)])
+        _lib.check(L.tgcn_cheb_wgrad_f32(_lib.stream_ptr(), M, Kc, N, nt, a, lda, _lib.ptr(g2d), g2d.stride(0),
+                                         _lib.ptr(dW[t0:]), _lib.ptr(ws), ws.numel()))
+    return dW
+
+
 def choose_layout(q, n, C_row):
     """layout 1 (re-lay x to one long row per vertex) when per-sample rows are short: gathers then move
     q*C contiguous floats per neighbour instead of C."""
@@ -171,28 +190,36 @@ class ChebLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        """All contractions run in libtgcn_hip.so: the basis is recomputed with the hop kernel, dW is the MFMA
+        weight-gradient kernel, G = g W^T is the projection kernel with the transposed weight, dx is Horner
+        (mode 0) / Clenshaw (mode 1) on L^T with the hop kernel; only the bias reduction is a torch sum."""
         x3, Wt = ctx.saved_tensors
         op, mode = ctx.op, ctx.mode
         K, Crow, N = Wt.shape
+        q, n, _ = x3.shape
         g = g.contiguous()
+        g2d = g.reshape(q * n, N)
         gx = gW = gb = None
         if ctx.needs_input_grad[1]:
             x3c = x3.contiguous()
             basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
-            gW = torch.einsum("kqnc,qng->kcg", basis, g)
+            gW = cheb_wgrad([basis[k].reshape(q * n, Crow) for k in range(K)], g2d)
         if ctx.needs_input_grad[0]:
             opT = op.transpose()
-            G = torch.einsum("qng,kcg->kqnc", g, Wt).contiguous()      # G_k = g W_k^T
+            # G[m, k*C + c] = sum_n g[m, n] W[k, c, n]: one projection with the (N, K*C) transposed weight
+            Wcat = Wt.permute(2, 0, 1).reshape(1, N, K * Crow).contiguous()
+            Gall = cheb_project([g2d], Wcat, None, BIAS_NONE, n).view(q, n, K * Crow)
+            G = [Gall[:, :, k * Crow:(k + 1) * Crow] for k in range(K)]        # strided views, rows contiguous
             if mode == MODE_POWER:                                       # Horner: b = G_j + L^T b
                 b = G[K - 1]
                 for j in range(K - 2, -1, -1):
                     b = csr_hop(opT, b, z=G[j], alpha=1.0, beta=1.0)
-                gx = b
+                gx = b.contiguous()
             elif K == 1:
-                gx = G[0]
+                gx = G[0].contiguous()
             else:                                                        # Clenshaw on L^T
-                b1 = torch.zeros_like(G[0])
-                b2 = torch.zeros_like(G[0])
+                b1 = torch.zeros((q, n, Crow), dtype=torch.float32, device=g.device)
+                b2 = torch.zeros_like(b1)
                 for k in range(K - 1, 0, -1):
                     t = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0)
                     t.add_(G[k])
