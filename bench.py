@@ -167,6 +167,17 @@ def main():
     bytes_recursion = (K - 1) * (8 * op.nnz + 4 * (op.n + 1) + 8 * op.n * F)
     n_hop_launches = len(hop_ms) // args.steps if hop_ms else 0
     roofline = None
+    small_ms = [ms for kind, ms in prof if kind == 4]
+    if small_ms and not hop_ms:
+        # one-launch LDS-resident path: the whole layer is one kernel; algorithmic bytes = SURVEY 8(d) whole-layer figure
+        bias_elems = layer.bias.numel() if layer.bias is not None else 0
+        layer_bytes = bytes_recursion + 4 * op.n * q * spec["g"] + 4 * K * C_row * spec["g"] + 4 * bias_elems
+        mean_ms = float(np.mean(small_ms))
+        achieved = layer_bytes / (mean_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="small_forward_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None, algorithmic_bytes_per_launch=int(layer_bytes),
+                        launches_per_step=len(small_ms) // args.steps, mean_launch_ms=round(mean_ms, 4),
+                        note="whole layer in one launch; hop tensors never leave LDS, so the HBM roofline on recursion bytes is nominal")
     if hop_ms:
         bytes_per_launch = bytes_recursion / n_hop_launches
         mean_ms = float(np.mean(hop_ms))

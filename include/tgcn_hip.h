@@ -89,6 +89,7 @@ int tgcn_abi_version(void);
 #define TGCN_PROF_HOP_FIXUP 1
 #define TGCN_PROF_PROJECT 2
 #define TGCN_PROF_RELAYOUT 3
+#define TGCN_PROF_SMALL 4
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 
@@ -145,6 +146,16 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
                           int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
                           const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
                           void* workspace, size_t workspace_bytes);
+
+/* Small graphs (n <= 1024, C <= 32, CSR + activations fit in 160 KB of LDS -- the reference's own MNIST / coarsened
+ * graphs): the whole layer in ONE launch, recursion run on the output side in LDS (Horner for mode 0, Clenshaw for
+ * mode 1).  W: (K, C, N) contiguous; `fold` (nullable, device, K x K): the reference_power -> monomial fold matrix,
+ * applied while the weight is staged so the caller passes the layer's raw weight.
+ * tgcn_cheb_forward_small_supported returns the channel tile (16 / 8) or 0 when the shape does not fit. */
+int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode);
+int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
+                                const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
+                                float* out);
 
 /* gcn_pool / gcn_pool_4 (gcn.py:246-255): max over p consecutive vertices; idx (nullable) receives the
  * arg-max offset 0..p-1 for the backward. */

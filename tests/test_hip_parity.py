@@ -259,6 +259,31 @@ def test_forward_layouts_agree(layout, q_chunk, gpu_device):
         assert rel_err(out.cpu().numpy(), ref) <= TOL
 
 
+@pytest.mark.parametrize("n,q,Crow,N,K", [(784, 5, 28, 64, 5), (300, 3, 1, 8, 5), (1000, 2, 32, 15, 3), (64, 7, 12, 70, 10), (500, 2, 5, 16, 1),
+                                          (200, 3, 17, 33, 25)])
+def test_small_graph_kernel_vs_oracle(n, q, Crow, N, K, gpu_device):
+    """The one-launch LDS-resident path (Horner / Clenshaw on the output side) against the oracle, both modes,
+    all bias kinds, in-kernel weight fold."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(n + K)
+    row, col, val = _random_graph(n, 6, rng, hubs=((3, 40),), isolated=(0, 9))
+    val = val * 0.5
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    assert F.small_path_tile(op, Crow, 0) in (8, 16)
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((q, n, Crow)).astype(np.float32)
+    W = (rng.standard_normal((K, Crow, N)) / np.sqrt(K * Crow)).astype(np.float32)
+    for kind, bias in ((0, None), (1, rng.standard_normal(N).astype(np.float32)), (2, rng.standard_normal((n, N)).astype(np.float32))):
+        for mode, stack in ((F.MODE_POWER, O.stack_reference_power), (F.MODE_CHEBYSHEV, O.stack_chebyshev)):
+            ref = np.einsum("kqnc,kcg->qng", stack(L.astype(np.float64), x.astype(np.float64), K), W.astype(np.float64))
+            if bias is not None:
+                ref = ref + bias
+            fold = F.power_fold_matrix(K, "cuda") if (mode == F.MODE_POWER and K > 2) else None
+            out = F.cheb_forward_small(op, _dev(x), _dev(W), fold, None if bias is None else _dev(bias), kind, mode)
+            assert rel_err(out.cpu().numpy(), ref) <= TOL, (kind, mode)
+
+
 # ------------------------------------------------------------------------------------------ backward
 @pytest.mark.parametrize("cls", ["GCNCheb", "TGCNCheb_H", "ChebConv", "ChebTimeConv"])
 def test_backward_vs_dense_autograd(cls, gpu_device):

@@ -57,6 +57,9 @@ SIGNATURES = {
     "tgcn_cheb_forward_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
                                         C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P,
                                         C.c_int32, C.c_int64, _P, C.c_size_t]),
+    "tgcn_cheb_forward_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_cheb_forward_small_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                              _P, _P, _P, _P, C.c_int32, _P]),
     "tgcn_pool_max_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_pool_max_bwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
 }

@@ -820,6 +820,167 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const WgradParams 
 }
 
 // --------------------------------------------------------------------------------------------------
+// small graphs: the whole layer in ONE launch, CSR and activations resident in LDS
+// --------------------------------------------------------------------------------------------------
+// Workgroup = (sample q, tile of NTC output channels).  The recursion runs on the OUTPUT side (n x NTC values in
+// LDS instead of n x C x K hop tensors in HBM):
+//   mode 0 (monomial-folded weight, Horner):  Y_j = X W_j + L Y_{j+1},                     out = Y_0 + bias
+//   mode 1 (Chebyshev weight, Clenshaw):      b_k = X W_k + 2 L b_{k+1} - b_{k+2},         out = X W_0 + L b_1 - b_2 + bias
+// Thread t owns vertex t (up to 1024 threads) and keeps its input row in registers; X W_j is VALU fmaf,
+// L . is a walk over the LDS-resident CSR reading neighbour rows of the previous buffer from LDS.
+constexpr int kSmallMaxN = 1024;  // one thread per vertex
+constexpr int kSmallCMax = 32;    // input row length held in registers
+
+struct SmallParams {
+  const int32_t* rowptr;
+  const tgcn_edge* ev;
+  const float* x;
+  const float* W;      // (K, C, N)
+  const float* fold;   // (K, K) or null: W'_j = sum_k fold[k][j] W_k applied while staging (mode 0)
+  const float* bias;
+  float* out;
+  int32_t n, nnz, q, K, C, N, mode, bias_kind;
+};
+
+template <int NTC, int CP>   // CP: input row length padded (registers), C <= CP
+__global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallParams p) {
+  extern __shared__ __align__(16) float smem[];
+  const int n = p.n, nnz = p.nnz, C = p.C;
+  const int nthr = blockDim.x;
+  // LDS carve-up (all offsets multiples of 4 floats)
+  tgcn_edge* ev = reinterpret_cast<tgcn_edge*>(smem);                      // nnz (padded to even)
+  int32_t* rowptr = reinterpret_cast<int32_t*>(smem + 2 * ((nnz + 1) / 2 * 2));
+  float* Wt = reinterpret_cast<float*>(rowptr) + (n + 1 + 3) / 4 * 4;       // C x NTC
+  float* Ybase = Wt + CP * NTC;                                     // NB buffers of n x NTC
+  const int nbuf = p.mode == 0 ? 2 : 3;
+  const int tid = threadIdx.x;       // == the vertex this thread owns
+  const int q = blockIdx.x, n0 = blockIdx.y * NTC;
+
+  // ---- stage CSR and this sample's input (through the Y buffers, which are free now) into LDS / registers
+  for (int e = tid; e < nnz; e += nthr) ev[e] = p.ev[e];
+  for (int i = tid; i <= n; i += nthr) rowptr[i] = p.rowptr[i];
+  float xr[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) xr[c] = 0.f;
+  {
+    const float* xq = p.x + (int64_t)q * n * C;
+    const int total = n * C, cap = nbuf * n * NTC;
+    for (int base = 0; base < total; base += cap) {     // one piece unless C > nbuf*NTC
+      const int cnt = min(cap, total - base);
+      __syncthreads();
+      for (int e = tid; e < cnt; e += nthr) Ybase[e] = xq[base + e];
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        const int e = tid * C + c - base;
+        if (tid < n && c < C && e >= 0 && e < cnt) xr[c] = Ybase[e];
+      }
+    }
+  }
+  __syncthreads();
+
+  int cur = 0;   // buffer that receives this step's result
+  for (int j = p.K - 1; j >= 0; --j) {
+    // ---- weight tile of this step -> LDS (folding the reference_power basis on the fly when asked to)
+    for (int e = tid; e < CP * NTC; e += nthr) {       // rows c >= C and columns >= N are zero
+      const int c = e / NTC, g = e % NTC;
+      float w = 0.f;
+      if (c < C && n0 + g < p.N) {
+        if (p.fold) {
+          for (int k = 0; k < p.K; ++k) w = fmaf(p.fold[k * p.K + j], p.W[((int64_t)k * C + c) * p.N + n0 + g], w);
+        } else {
+          w = p.W[((int64_t)j * C + c) * p.N + n0 + g];
+        }
+      }
+      Wt[e] = w;
+    }
+    __syncthreads();
+    const bool first = (j == p.K - 1);
+    const float alpha = (p.mode == 1 && j > 0) ? 2.f : 1.f;
+    const bool sub = (p.mode == 1) && (j <= p.K - 3);              // b_{k+2} exists
+    const float* B1 = Ybase + ((cur + nbuf - 1) % nbuf) * n * NTC;  // previous result
+    const float* B2 = Ybase + ((cur + nbuf - 2) % nbuf) * n * NTC;  // the one before (mode 1)
+    float* Yn = Ybase + cur * n * NTC;
+    const int i = tid;
+    if (i < n) {
+      float acc[NTC];
+#pragma unroll
+      for (int g = 0; g < NTC; ++g) acc[g] = 0.f;
+      if (!first) {                                   // alpha * (L B1)[i]
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+          const tgcn_edge ed = ev[e];
+          const float4* src = reinterpret_cast<const float4*>(B1 + ed.col * NTC);
+          const int sw = (ed.col >> 2) & (NTC / 4 - 1);   // rows are stored with their 16-byte quads XOR-swizzled
+#pragma unroll
+          for (int g4 = 0; g4 < NTC / 4; ++g4) {
+            const float4 y = src[g4 ^ sw];
+            acc[g4 * 4 + 0] = fmaf(ed.val, y.x, acc[g4 * 4 + 0]);
+            acc[g4 * 4 + 1] = fmaf(ed.val, y.y, acc[g4 * 4 + 1]);
+            acc[g4 * 4 + 2] = fmaf(ed.val, y.z, acc[g4 * 4 + 2]);
+            acc[g4 * 4 + 3] = fmaf(ed.val, y.w, acc[g4 * 4 + 3]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < NTC; ++g) acc[g] *= alpha;
+        if (sub) {
+          const int swi = (i >> 2) & (NTC / 4 - 1);
+#pragma unroll
+          for (int g4 = 0; g4 < NTC / 4; ++g4) {
+            const float4 z = reinterpret_cast<const float4*>(B2 + i * NTC)[g4 ^ swi];
+            acc[g4 * 4 + 0] -= z.x; acc[g4 * 4 + 1] -= z.y; acc[g4 * 4 + 2] -= z.z; acc[g4 * 4 + 3] -= z.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {                  // + X W_j  (padded rows of Wt are zero: no per-c condition)
+        const float xv = xr[c];
+        const float4* wrow = reinterpret_cast<const float4*>(Wt + c * NTC);
+#pragma unroll
+        for (int g4 = 0; g4 < NTC / 4; ++g4) {
+          const float4 w = wrow[g4];
+          acc[g4 * 4 + 0] = fmaf(xv, w.x, acc[g4 * 4 + 0]);
+          acc[g4 * 4 + 1] = fmaf(xv, w.y, acc[g4 * 4 + 1]);
+          acc[g4 * 4 + 2] = fmaf(xv, w.z, acc[g4 * 4 + 2]);
+          acc[g4 * 4 + 3] = fmaf(xv, w.w, acc[g4 * 4 + 3]);
+        }
+        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled LDS reads from piling up in registers
+      }
+      if (j > 0) {
+        const int swi = (i >> 2) & (NTC / 4 - 1);
+#pragma unroll
+        for (int g4 = 0; g4 < NTC / 4; ++g4)
+          reinterpret_cast<float4*>(Yn + i * NTC)[g4 ^ swi] = make_float4(acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+      } else {                                        // last step: bias and straight to HBM
+        float* o = p.out + ((int64_t)q * n + i) * p.N + n0;
+        const float* bp = p.bias_kind == 1 ? p.bias + n0 : (p.bias_kind == 2 ? p.bias + (int64_t)i * p.N + n0 : nullptr);
+        if (n0 + NTC <= p.N && (p.N & 3) == 0) {      // whole tile, 16-byte stores
+#pragma unroll
+          for (int g4 = 0; g4 < NTC / 4; ++g4) {
+            float4 v4 = make_float4(acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+            if (bp) { v4.x += bp[g4 * 4]; v4.y += bp[g4 * 4 + 1]; v4.z += bp[g4 * 4 + 2]; v4.w += bp[g4 * 4 + 3]; }
+            reinterpret_cast<float4*>(o)[g4] = v4;
+          }
+        } else {
+          for (int g = 0; g < NTC; ++g)               // ragged last tile: through LDS to keep register indices static
+            Yn[i * NTC + g] = 0.f;
+#pragma unroll
+          for (int g = 0; g < NTC; ++g) Yn[i * NTC + g] = acc[g];
+          for (int g = 0; g < NTC && n0 + g < p.N; ++g) o[g] = Yn[i * NTC + g] + (bp ? bp[g] : 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    cur = (cur + 1) % nbuf;
+  }
+}
+
+inline size_t small_lds_bytes(int n, int nnz, int ntc, int mode) {
+  const size_t fl = 2 * (size_t)((nnz + 1) / 2 * 2) + (size_t)((n + 1 + 3) / 4 * 4) + (size_t)kSmallCMax * ntc +
+                    (size_t)(mode == 0 ? 2 : 3) * n * ntc;
+  return fl * sizeof(float);
+}
+
+// --------------------------------------------------------------------------------------------------
 // relayout (Q,n,C) -> (n,Q,C), C <= 32
 // --------------------------------------------------------------------------------------------------
 constexpr int kRelT = 16;
@@ -1113,6 +1274,44 @@ static void fwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t
   const int32_t Crow = layout == 1 ? (int32_t)(q * C) : C;
   o += align_up(tgcn_csr_hop_workspace_bytes(S, nb, Crow, 1), 256);
   *total = o;
+}
+
+int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode) {
+  if (n < 1 || n > (int64_t)kSmallMaxN || nnz < 0 || nnz > (1 << 20) || C < 1 || C > kSmallCMax) return 0;
+  if (mode != 0 && mode != 1) return 0;
+  if (small_lds_bytes((int)n, (int)nnz, 16, mode) <= 160 * 1024) return 16;
+  if (small_lds_bytes((int)n, (int)nnz, 8, mode) <= 160 * 1024) return 8;
+  return 0;
+}
+
+int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
+                                const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
+                                float* out) {
+  if (!A || !x || !W || !out || K < 1 || q < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bad argument");
+  if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bias_kind %d", bias_kind);
+  if (fold && mode != 0) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: fold is for mode 0");
+  const int ntc = tgcn_cheb_forward_small_supported(A->n, A->nnz, C, mode);
+  if (!ntc) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: n=%lld nnz=%lld C=%d does not fit in LDS", (long long)A->n, (long long)A->nnz, C);
+  if (q > 2147483647LL || (N + ntc - 1) / ntc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: grid too large");
+  SmallParams p;
+  p.rowptr = A->rowptr; p.ev = A->edges; p.x = x; p.W = W; p.fold = fold; p.bias = bias; p.out = out;
+  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.N = N; p.mode = mode; p.bias_kind = bias_kind;
+  const size_t lds = small_lds_bytes(p.n, p.nnz, ntc, mode);
+  const dim3 grid((unsigned)q, (unsigned)((N + ntc - 1) / ntc));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nthreads = (unsigned)((p.n + 63) / 64 * 64);
+  ProfScope ps(TGCN_PROF_SMALL, st);
+#define TGCN_SMALL(NTCV, CPV)                                                                                     \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    if (!attr) { hipFuncSetAttribute((const void*)small_forward_kernel<NTCV, CPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((small_forward_kernel<NTCV, CPV>), grid, dim3(nthreads), lds, st, p);                      \
+  }
+  if (ntc == 16) { if (C <= 4) TGCN_SMALL(16, 4) else if (C <= 16) TGCN_SMALL(16, 16) else TGCN_SMALL(16, 32) }
+  else { if (C <= 4) TGCN_SMALL(8, 4) else if (C <= 16) TGCN_SMALL(8, 16) else TGCN_SMALL(8, 32) }
+#undef TGCN_SMALL
+  TGCN_CHECK_LAUNCH("tgcn_cheb_forward_small_f32");
+  return TGCN_OK;
 }
 
 size_t tgcn_cheb_forward_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t C,

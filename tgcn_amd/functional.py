@@ -173,18 +173,43 @@ def _power_fold_matrix(K, device=None, dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------------------- autograd
+def small_path_tile(op, C_row, mode):
+    """Channel tile (16 / 8) of the one-launch LDS-resident kernel, or 0 when the shape does not fit it."""
+    if op.n_cols != op.n:
+        return 0
+    return _lib.lib().tgcn_cheb_forward_small_supported(op.n, op.nnz, int(C_row), int(mode))
+
+
+def cheb_forward_small(op, x3, W_kcn, fold, bias, bias_kind, mode):
+    """Whole layer in one launch (tgcn_cheb_forward_small_f32).  W_kcn: (K, C, N) RAW weight when `fold` is given."""
+    _lib.require_device(x3, W_kcn, bias, fold)
+    q, n, Crow = x3.shape
+    K, _, N = W_kcn.shape
+    out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
+    _lib.check(_lib.lib().tgcn_cheb_forward_small_f32(_lib.stream_ptr(), C.byref(op.struct), mode, K, q, Crow, N, _lib.ptr(x3),
+                                                      _lib.ptr(W_kcn), _lib.ptr(fold), _lib.ptr(bias), bias_kind, _lib.ptr(out)))
+    return out
+
+
 class ChebLayerFn(torch.autograd.Function):
-    """out = sum_k T_k x W_k + bias with T_k given by `mode`; x3 (q,n,C), Wt (K, C, N) already folded for
-    MODE_POWER.  Backward: the same HIP hop kernel on L^T for dx (Horner / Clenshaw), library GEMMs for the
-    dense contractions."""
+    """out = sum_k T_k x W_k + bias with T_k given by `mode`; x3 (q,n,C), W (K, C, N) in the REFERENCE basis.
+    For MODE_POWER the weight is folded to the monomial basis (W'_j = sum_k c[k,j] W_k): inside the kernel on the
+    small-graph path, by a tiny einsum otherwise; backward applies the transposed fold to the weight gradient."""
 
     @staticmethod
-    def forward(ctx, x3, Wt, bias, op, mode, bias_kind):
-        K, Crow, N = Wt.shape
-        out = cheb_forward_raw(op, x3.contiguous(), Wt.reshape(K * Crow, N).contiguous(),
-                               bias.contiguous() if bias is not None else None, bias_kind, mode, K)
-        ctx.save_for_backward(x3, Wt)
-        ctx.op, ctx.mode, ctx.bias_kind = op, mode, bias_kind
+    def forward(ctx, x3, W, bias, op, mode, bias_kind):
+        K, Crow, N = W.shape
+        x3 = x3.contiguous()
+        W = W.contiguous()
+        b = bias.contiguous() if bias is not None else None
+        fold = power_fold_matrix(K, W.device) if (mode == MODE_POWER and K > 2) else None
+        if small_path_tile(op, Crow, mode):
+            out = cheb_forward_small(op, x3, W, fold, b, bias_kind, mode)
+        else:
+            Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W
+            out = cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
+        ctx.save_for_backward(x3, W)
+        ctx.op, ctx.mode, ctx.bias_kind, ctx.fold = op, mode, bias_kind, fold
         ctx.bias_shape = None if bias is None else bias.shape
         return out
 
@@ -193,8 +218,9 @@ class ChebLayerFn(torch.autograd.Function):
         """All contractions run in libtgcn_hip.so: the basis is recomputed with the hop kernel, dW is the MFMA
         weight-gradient kernel, G = g W^T is the projection kernel with the transposed weight, dx is Horner
         (mode 0) / Clenshaw (mode 1) on L^T with the hop kernel; only the bias reduction is a torch sum."""
-        x3, Wt = ctx.saved_tensors
-        op, mode = ctx.op, ctx.mode
+        x3, W = ctx.saved_tensors
+        op, mode, fold = ctx.op, ctx.mode, ctx.fold
+        Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W      # the basis the kernels work in
         K, Crow, N = Wt.shape
         q, n, _ = x3.shape
         g = g.contiguous()
@@ -204,6 +230,8 @@ class ChebLayerFn(torch.autograd.Function):
             x3c = x3.contiguous()
             basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
             gW = cheb_wgrad([basis[k].reshape(q * n, Crow) for k in range(K)], g2d)
+            if fold is not None:                                          # back to the reference basis
+                gW = torch.einsum("kj,jcn->kcn", fold, gW)
         if ctx.needs_input_grad[0]:
             opT = op.transpose()
             # G[m, k*C + c] = sum_n g[m, n] W[k, c, n]: one projection with the (N, K*C) transposed weight
@@ -241,12 +269,7 @@ def _monomial_stack(op, x3, K):
 
 
 def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode):
-    """Differentiable fused layer.  weight_kcn: (K, C, N) in the REFERENCE basis; for MODE_POWER it is folded to
-    the monomial basis here with a differentiable einsum, so autograd returns the gradient in the reference basis."""
-    K = weight_kcn.shape[0]
-    if mode == MODE_POWER and K > 2:
-        c = power_fold_matrix(K, weight_kcn.device)
-        weight_kcn = torch.einsum("kj,kcn->jcn", c, weight_kcn)
+    """Differentiable fused layer; weight_kcn: (K, C, N) in the reference basis."""
     return ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind)
 
 
