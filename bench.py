@@ -41,6 +41,15 @@ def build_workload(name, labeling, device, n_override=None, nnz_override=None):
     elif name == "cfg4":
         n, row, col, val = synth.sheet_mesh(300, device=device)
         spec = dict(cls="TGCNCheb_H", q=1, H=1200, f=1, g=32, K=5, desc="sheet mesh n=90000 nnz=%d, TGCNCheb_H(L,1,32,5,1200), q=1" % row.numel())
+    elif name == "hcp148":
+        # the reference's own HCP model shape: TGCNCheb_H(L, 1, 32, 10, 15) on the 148-parcel DTI graph, batch 512
+        # (examples/pytorch_based/pytorch_hcp_tgcn.py:103-104,242); graph = fixture generated from load/res/*.mat
+        z = np.load(os.path.join(ROOT, "tests", "golden", "TGCNChebH_dti148_q4_f1_g32_K10_H15.npz"))
+        n = int(z["n"])
+        rowptr = torch.as_tensor(z["rowptr"])
+        row = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1]).to(device)
+        col, val = torch.as_tensor(z["col"]).long().to(device), torch.as_tensor(z["val"]).to(device)
+        spec = dict(cls="TGCNCheb_H", q=512, H=15, f=1, g=32, K=10, desc="HCP aparc DTI graph n=148 nnz=%d (dense), TGCNCheb_H(L,1,32,10,15), q=512" % col.numel())
     elif name in ("cfg3", "cfg2"):
         z = np.load(os.path.join(ROOT, "tests", "golden", "GCNCheb_grid784_q3_f1_g8_K5_x2d.npz"))
         n = int(z["n"])
@@ -114,6 +123,7 @@ def main():
     ap.add_argument("--n", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
     ap.add_argument("--nnz", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-small-path", action="store_true", help="developer: disable the one-launch small-graph kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +137,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    from tgcn_amd import _lib
+    from tgcn_amd import _lib, functional as _F
+    if args.no_small_path:
+        _F.SMALL_PATH = False
     op, spec = build_workload(args.workload, args.labeling, device, args.n, args.nnz)
     layer = make_layer(op, spec, device)
     x = make_input(op, spec, device, seed=rank)

@@ -839,7 +839,7 @@ struct SmallParams {
   const float* fold;   // (K, K) or null: W'_j = sum_k fold[k][j] W_k applied while staging (mode 0)
   const float* bias;
   float* out;
-  int32_t n, nnz, q, K, C, N, mode, bias_kind;
+  int32_t n, nnz, q, K, C, N, mode, bias_kind, dense, spw, npad;   // spw samples per workgroup, npad threads per sample
 };
 
 template <int NTC, int CP>   // CP: input row length padded (registers), C <= CP
@@ -848,32 +848,47 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
   const int n = p.n, nnz = p.nnz, C = p.C;
   const int nthr = blockDim.x;
   // LDS carve-up (all offsets multiples of 4 floats)
+  // graph region: CSR (entries + rowptr), or -- for dense small operands such as the 148-vertex DTI graph of
+  // load/res -- the operand as a dense n x ldn matrix (ldn odd: a column read by all threads is conflict-free)
+  const int ldn = n | 1;
   tgcn_edge* ev = reinterpret_cast<tgcn_edge*>(smem);                      // nnz (padded to even)
   int32_t* rowptr = reinterpret_cast<int32_t*>(smem + 2 * ((nnz + 1) / 2 * 2));
-  float* Wt = reinterpret_cast<float*>(rowptr) + (n + 1 + 3) / 4 * 4;       // C x NTC
-  float* Ybase = Wt + CP * NTC;                                     // NB buffers of n x NTC
+  float* Ld = smem;
+  float* Wt = p.dense ? smem + (n * ldn + 3) / 4 * 4 : reinterpret_cast<float*>(rowptr) + (n + 1 + 3) / 4 * 4;   // CP x NTC
   const int nbuf = p.mode == 0 ? 2 : 3;
-  const int tid = threadIdx.x;       // == the vertex this thread owns
-  const int q = blockIdx.x, n0 = blockIdx.y * NTC;
+  const int tid = threadIdx.x;
+  // the workgroup runs spw samples side by side (occupancy for small n); thread = (sample slot, vertex)
+  const int slot = tid / p.npad, li = tid % p.npad;
+  const int q = blockIdx.x * p.spw + slot, n0 = blockIdx.y * NTC;
+  const bool live = q < p.q;
+  float* Ybase = Wt + CP * NTC + slot * (nbuf * n * NTC);            // this sample's NB buffers of n x NTC
 
   // ---- stage CSR and this sample's input (through the Y buffers, which are free now) into LDS / registers
-  for (int e = tid; e < nnz; e += nthr) ev[e] = p.ev[e];
-  for (int i = tid; i <= n; i += nthr) rowptr[i] = p.rowptr[i];
+  if (p.dense) {
+    for (int e = tid; e < n * ldn; e += nthr) Ld[e] = 0.f;
+    __syncthreads();
+    if (tid < n)    // first n threads: one row each (own row only, no atomics)
+      for (int e = p.rowptr[tid]; e < p.rowptr[tid + 1]; ++e) Ld[tid * ldn + p.ev[e].col] += p.ev[e].val;
+  } else {
+    for (int e = tid; e < nnz; e += nthr) ev[e] = p.ev[e];
+    for (int i = tid; i <= n; i += nthr) rowptr[i] = p.rowptr[i];
+  }
   float xr[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) xr[c] = 0.f;
   {
-    const float* xq = p.x + (int64_t)q * n * C;
+    const float* xq = p.x + (int64_t)(live ? q : 0) * n * C;
     const int total = n * C, cap = nbuf * n * NTC;
     for (int base = 0; base < total; base += cap) {     // one piece unless C > nbuf*NTC
       const int cnt = min(cap, total - base);
       __syncthreads();
-      for (int e = tid; e < cnt; e += nthr) Ybase[e] = xq[base + e];
+      if (live)
+        for (int e = li; e < cnt; e += p.npad) Ybase[e] = xq[base + e];
       __syncthreads();
 #pragma unroll
       for (int c = 0; c < CP; ++c) {
-        const int e = tid * C + c - base;
-        if (tid < n && c < C && e >= 0 && e < cnt) xr[c] = Ybase[e];
+        const int e = li * C + c - base;
+        if (live && li < n && c < C && e >= 0 && e < cnt) xr[c] = Ybase[e];
       }
     }
   }
@@ -901,12 +916,26 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
     const float* B1 = Ybase + ((cur + nbuf - 1) % nbuf) * n * NTC;  // previous result
     const float* B2 = Ybase + ((cur + nbuf - 2) % nbuf) * n * NTC;  // the one before (mode 1)
     float* Yn = Ybase + cur * n * NTC;
-    const int i = tid;
-    if (i < n) {
+    const int i = li;
+    if (live && i < n) {
       float acc[NTC];
 #pragma unroll
       for (int g = 0; g < NTC; ++g) acc[g] = 0.f;
-      if (!first) {                                   // alpha * (L B1)[i]
+      if (!first && p.dense) {                        // alpha * (L B1)[i], dense operand: B1 rows are LDS broadcasts
+        for (int col = 0; col < n; ++col) {
+          const float lv = Ld[i * ldn + col];
+          const float4* src = reinterpret_cast<const float4*>(B1 + col * NTC);
+          const int sw = (col >> 2) & (NTC / 4 - 1);
+#pragma unroll
+          for (int g4 = 0; g4 < NTC / 4; ++g4) {
+            const float4 y = src[g4 ^ sw];
+            acc[g4 * 4 + 0] = fmaf(lv, y.x, acc[g4 * 4 + 0]);
+            acc[g4 * 4 + 1] = fmaf(lv, y.y, acc[g4 * 4 + 1]);
+            acc[g4 * 4 + 2] = fmaf(lv, y.z, acc[g4 * 4 + 2]);
+            acc[g4 * 4 + 3] = fmaf(lv, y.w, acc[g4 * 4 + 3]);
+          }
+        }
+      } else if (!first) {                            // alpha * (L B1)[i], CSR walk
         for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
           const tgcn_edge ed = ev[e];
           const float4* src = reinterpret_cast<const float4*>(B1 + ed.col * NTC);
@@ -920,6 +949,8 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
             acc[g4 * 4 + 3] = fmaf(ed.val, y.w, acc[g4 * 4 + 3]);
           }
         }
+      }
+      if (!first) {
 #pragma unroll
         for (int g = 0; g < NTC; ++g) acc[g] *= alpha;
         if (sub) {
@@ -974,10 +1005,27 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
   }
 }
 
-inline size_t small_lds_bytes(int n, int nnz, int ntc, int mode) {
-  const size_t fl = 2 * (size_t)((nnz + 1) / 2 * 2) + (size_t)((n + 1 + 3) / 4 * 4) + (size_t)kSmallCMax * ntc +
-                    (size_t)(mode == 0 ? 2 : 3) * n * ntc;
+inline size_t small_lds_bytes(int n, int nnz, int ntc, int mode, int dense, int spw = 1) {
+  const size_t graph = dense ? (size_t)((n * (n | 1) + 3) / 4 * 4)
+                             : 2 * (size_t)((nnz + 1) / 2 * 2) + (size_t)((n + 1 + 3) / 4 * 4);
+  const size_t fl = graph + (size_t)kSmallCMax * ntc + (size_t)spw * (mode == 0 ? 2 : 3) * n * ntc;
   return fl * sizeof(float);
+}
+
+// -> channel tile (16 / 8), *dense set to the cheaper LDS form of the operand; 0 when nothing fits
+inline int small_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int* dense) {
+  if (n < 1 || n > (int64_t)kSmallMaxN || nnz < 0 || nnz > (1 << 20) || C < 1 || C > kSmallCMax) return 0;
+  if (mode != 0 && mode != 1) return 0;
+  for (int ntc = 16; ntc >= 8; ntc /= 2) {
+    const size_t sparse_b = small_lds_bytes((int)n, (int)nnz, ntc, mode, 0);
+    const size_t dense_b = n <= 512 ? small_lds_bytes((int)n, (int)nnz, ntc, mode, 1) : (size_t)-1;
+    const size_t best = sparse_b < dense_b ? sparse_b : dense_b;
+    if (best <= 160 * 1024) {
+      *dense = dense_b < sparse_b;
+      return ntc;
+    }
+  }
+  return 0;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1277,11 +1325,8 @@ static void fwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t
 }
 
 int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode) {
-  if (n < 1 || n > (int64_t)kSmallMaxN || nnz < 0 || nnz > (1 << 20) || C < 1 || C > kSmallCMax) return 0;
-  if (mode != 0 && mode != 1) return 0;
-  if (small_lds_bytes((int)n, (int)nnz, 16, mode) <= 160 * 1024) return 16;
-  if (small_lds_bytes((int)n, (int)nnz, 8, mode) <= 160 * 1024) return 8;
-  return 0;
+  int dense = 0;
+  return small_config(n, nnz, C, mode, &dense);
 }
 
 int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
@@ -1290,16 +1335,25 @@ int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, i
   if (!A || !x || !W || !out || K < 1 || q < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bad argument");
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bias_kind %d", bias_kind);
   if (fold && mode != 0) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: fold is for mode 0");
-  const int ntc = tgcn_cheb_forward_small_supported(A->n, A->nnz, C, mode);
+  int dense = 0;
+  const int ntc = small_config(A->n, A->nnz, C, mode, &dense);
   if (!ntc) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: n=%lld nnz=%lld C=%d does not fit in LDS", (long long)A->n, (long long)A->nnz, C);
   if (q > 2147483647LL || (N + ntc - 1) / ntc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: grid too large");
   SmallParams p;
   p.rowptr = A->rowptr; p.ev = A->edges; p.x = x; p.W = W; p.fold = fold; p.bias = bias; p.out = out;
-  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.N = N; p.mode = mode; p.bias_kind = bias_kind;
-  const size_t lds = small_lds_bytes(p.n, p.nnz, ntc, mode);
-  const dim3 grid((unsigned)q, (unsigned)((N + ntc - 1) / ntc));
+  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.N = N; p.mode = mode; p.bias_kind = bias_kind; p.dense = dense;
+  // samples per workgroup: as many as fit the 1024-thread / 160 KB budget, but keep >= 512 workgroups in the grid
+  p.npad = (p.n + 63) / 64 * 64;
+  int spw = 1;
+  const int64_t col_tiles = (N + ntc - 1) / ntc;
+  while ((spw + 1) * p.npad <= kSmallMaxN && small_lds_bytes(p.n, p.nnz, ntc, mode, dense, spw + 1) <= 160 * 1024 &&
+         (q + spw) / (spw + 1) * col_tiles >= 512)
+    ++spw;
+  p.spw = spw;
+  const size_t lds = small_lds_bytes(p.n, p.nnz, ntc, mode, dense, spw);
+  const dim3 grid((unsigned)((q + spw - 1) / spw), (unsigned)col_tiles);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nthreads = (unsigned)((p.n + 63) / 64 * 64);
+  const unsigned nthreads = (unsigned)(p.npad * p.spw);
   ProfScope ps(TGCN_PROF_SMALL, st);
 #define TGCN_SMALL(NTCV, CPV)                                                                                     \
   {                                                                                                               \

@@ -10,6 +10,7 @@ import torch
 from . import _lib
 from .graph import GraphOperand
 
+SMALL_PATH = True   # developer switch (tools/): route small graphs through the general multi-launch path instead
 MODE_POWER = 0      # dense-L classes: Xt[k] = 2 L^k x - Xt[k-2]  (tgcn/nn/gcn.py:75-78,150-153,233-236)
 MODE_CHEBYSHEV = 1  # edge-list classes: Tx_k = 2 L Tx_{k-1} - Tx_{k-2}  (gcn.py:427-432,524-528)
 BIAS_NONE, BIAS_CHANNEL, BIAS_VERTEX_CHANNEL = 0, 1, 2
@@ -175,7 +176,7 @@ def _power_fold_matrix(K, device=None, dtype=torch.float32):
 # ----------------------------------------------------------------------------------------- autograd
 def small_path_tile(op, C_row, mode):
     """Channel tile (16 / 8) of the one-launch LDS-resident kernel, or 0 when the shape does not fit it."""
-    if op.n_cols != op.n:
+    if op.n_cols != op.n or not SMALL_PATH:
         return 0
     return _lib.lib().tgcn_cheb_forward_small_supported(op.n, op.nnz, int(C_row), int(mode))
 
