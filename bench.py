@@ -120,9 +120,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg5")
     ap.add_argument("--labeling", default="random")
-    ap.add_argument("--n", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
-    ap.add_argument("--nnz", type=int, default=None)
+    ap.add_argument("--vertices", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
+    ap.add_argument("--entries", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--shard", default="time", choices=["time", "vertex"], help="N > 1: time steps per rank (no collective, weak scaling) or vertex rows per rank with a halo / all-gather exchange per hop (strong scaling)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-small-path", action="store_true", help="developer: disable the one-launch small-graph kernel")
     args = ap.parse_args()
 
@@ -130,20 +132,47 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    local = local % torch.cuda.device_count()      # rehearsals may put several ranks on one card
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from tgcn_amd import _lib, functional as _F
     if args.no_small_path:
         _F.SMALL_PATH = False
-    op, spec = build_workload(args.workload, args.labeling, device, args.n, args.nnz)
-    layer = make_layer(op, spec, device)
-    x = make_input(op, spec, device, seed=rank)
+    op, spec = build_workload(args.workload, args.labeling, device, args.vertices, args.entries)
     K, q, H = spec["K"], spec["q"], spec["H"]
+    vertex_mode = world > 1 and args.shard == "vertex"
+    if vertex_mode:
+        # every rank holds the same seeded graph; rank r owns an nnz-balanced row range and its slice of x / bias
+        from tgcn_amd.dist import VertexShardedCheb
+        assert spec["cls"] == "TGCNCheb", "vertex sharding bench is wired for the cfg5 layer"
+        row, col, val = op.coo()
+        sh = VertexShardedCheb(op.n, row, col, val, device=device, exchange="auto")
+        del row, col, val
+        torch.manual_seed(1)
+        import tgcn_amd
+        Wraw = torch.empty(K, spec["f"], spec["g"], device=device)
+        tgcn_amd.uniform(spec["f"] * K, Wraw)
+        Wf = torch.einsum("kj,kcn->jcn", _F.power_fold_matrix(K, device), Wraw).contiguous()
+        bias_local = torch.zeros(sh.owned, spec["g"], device=device)
+        g = torch.Generator(device=device).manual_seed(rank)
+        x_local = torch.randn((q, sh.owned, spec["f"]), device=device, generator=g)
+
+        class _Sharded:
+            bias = None
+            def __call__(self, _x):
+                return sh.forward(x_local, Wf, bias_local, 2, 0)
+        layer, x = _Sharded(), None
+    else:
+        layer = make_layer(op, spec, device)
+        x = make_input(op, spec, device, seed=rank)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -163,12 +192,12 @@ def main():
         dt = time.perf_counter() - t0
         prof = _lib.profile_stop(65536)
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     units_per_step = op.nnz * (K - 1) * q * H            # edge.timesteps per forward per rank
-    value = world * units_per_step * args.steps / dt / 1e9
+    value = (1 if vertex_mode else world) * units_per_step * args.steps / dt / 1e9   # vertex mode: ONE graph over all ranks
 
     # ---- roofline of the dominant kernel (hop_kernel): algorithmic bytes per launch / mean launch duration
     hop_ms = [ms for kind, ms in prof if kind == 0]
@@ -176,7 +205,8 @@ def main():
     fix_ms = [ms for kind, ms in prof if kind == 1]
     C_row = H * spec["f"]
     F = q * C_row
-    bytes_recursion = (K - 1) * (8 * op.nnz + 4 * (op.n + 1) + 8 * op.n * F)
+    nnz_l, n_l = (sh.op.nnz, sh.owned) if vertex_mode else (op.nnz, op.n)      # what ONE rank's launches process
+    bytes_recursion = (K - 1) * (8 * nnz_l + 4 * (n_l + 1) + 8 * n_l * F)
     n_hop_launches = len(hop_ms) // args.steps if hop_ms else 0
     roofline = None
     small_ms = [ms for kind, ms in prof if kind == 4]
@@ -195,7 +225,9 @@ def main():
         mean_ms = float(np.mean(hop_ms))
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, args.labeling))
+        tpath = ""
+        if args.vertices is None and args.entries is None and not vertex_mode:
+            tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, args.labeling))
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_hop_launch")
         roofline = dict(bound="hbm", kernel="hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
@@ -216,10 +248,10 @@ def main():
     if rank == 0:
         line = dict(metric="Cheb-TGCN fwd: G edge.timesteps/s + achieved HBM GB/s, K=5 on 160M-edge graph",
                     value=round(value, 3), unit="G edge.timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if vertex_mode else "weak", vs_baseline=None,
                     dtype="f32", data="synthetic",
                     config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
-                                sharding="time steps across ranks, CSR replicated, no collective" if world > 1 else "single GPU",
+                                sharding=("vertex rows across ranks, %s exchange per hop" % sh.exchange) if vertex_mode else ("time steps across ranks, CSR replicated, no collective" if world > 1 else "single GPU"),
                                 nnz=op.nnz, n=op.n),
                     roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line))
