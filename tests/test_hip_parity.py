@@ -162,6 +162,30 @@ def test_hop_vs_oracle(nb, n, C, gpu_device):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("C", [64, 300, 28])
+def test_hop_banded_graph_vs_oracle(C, gpu_device):
+    """Operand with locality (banded + a few long-range entries + one long row), n large enough for several row blocks."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(C)
+    n = 6000
+    row = np.repeat(np.arange(n), 7)
+    col = np.clip(row + rng.integers(-5, 6, row.shape[0]), 0, n - 1)
+    extra = rng.integers(0, n, (2, 400))
+    row = np.concatenate([row, extra[0], np.full(900, 1234)])
+    col = np.concatenate([col, extra[1], rng.integers(0, n, 900)])
+    val = rng.standard_normal(row.shape[0]).astype(np.float32) / 3
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((2, n, C)).astype(np.float32)
+    z = rng.standard_normal((2, n, C)).astype(np.float32)
+    s = O._apply(L, x)
+    y, p = F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0, want_p=True)
+    assert rel_err(p.cpu().numpy(), s) <= TOL
+    assert rel_err(y.cpu().numpy(), 2 * s - z) <= TOL
+    assert torch.equal(y, F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0))
+
+
 def test_hop_linearity_large(gpu_device):
     """Size-independent property at a size the oracle would not finish quickly: L(a x1 + x2) = a L x1 + L x2."""
     from tgcn_amd import functional as F
