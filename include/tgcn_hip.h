@@ -122,6 +122,16 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
                           const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                           int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo);
 
+/* Streaming time windows (replaces materialising the T-H+1 overlapping windows of
+ * load/data_hcp.py:116-154 and running TGCNCheb_H on each): series[t] are the hop tensors of ONE recording,
+ * (n_vertices, T) contiguous (term t = L^t applied to the raw series); window w of vertex i is series[t][i, w:w+H].
+ *   out[w, i, :] = sum_t series[t][i, w:w+H] . W[t*H:(t+1)*H, :] + bias       out: (T-H+1, n_vertices, N)
+ * i.e. exactly what the layer returns for the windowed batch, with the K-1 hops done once on T columns instead
+ * of (T-H+1)*H. */
+int tgcn_cheb_project_windows_f32(void* stream, int64_t n_vertices, int32_t T, int32_t H, int32_t N, int32_t nterms,
+                                  const float* const* series, const float* W, const float* bias, int32_t bias_kind,
+                                  float* out);
+
 /* Weight gradient of the projection (backward of gcn.py:39,113,194 w.r.t. weight):
  *   dW[t*Kc + c, n] = sum_m A_t[m, c] * G[m, n]
  * A_t as in tgcn_cheb_project_f32 (host arrays of nterms <= 32 pointers / strides), G: M x N with row stride ldg,

@@ -308,6 +308,26 @@ def test_small_graph_kernel_vs_oracle(n, q, Crow, N, K, gpu_device):
             assert rel_err(out.cpu().numpy(), ref) <= TOL, (kind, mode)
 
 
+@pytest.mark.parametrize("n,S,T,H,g,K", [(148, 2, 60, 15, 32, 10), (784, 1, 40, 12, 15, 5), (300, 3, 33, 7, 8, 3)])
+def test_streaming_windows_match_windowed_batch(n, S, T, H, g, K, gpu_device):
+    """forward_series(series) == layer(windowed batch) == oracle on the windowed batch (load/data_hcp.py:146-152)."""
+    import tgcn_amd
+    rng = np.random.default_rng(n + T)
+    row, col, val = _random_graph(n, 6, rng, hubs=((2, 60),))
+    val = val * 0.4
+    L = O.coo_to_csr(row, col, val, n)
+    layer = tgcn_amd.TGCNCheb_H(torch.tensor(L.toarray(), dtype=torch.float32), 1, g, K, H).cuda()
+    series = rng.standard_normal((S, n, T)).astype(np.float32)
+    nwin = T - H + 1
+    xw = np.stack([series[s, :, w:w + H] for s in range(S) for w in range(nwin)])          # (S*nwin, n, H)
+    ref = O.tgcn_cheb_h_forward(L, xw, layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy())
+    with torch.no_grad():
+        out_stream = layer.forward_series(_dev(series))
+        out_batch = layer(_dev(xw))
+    assert rel_err(out_stream.cpu().numpy(), ref) <= TOL
+    assert rel_err(out_batch.cpu().numpy(), ref) <= TOL
+
+
 # ------------------------------------------------------------------------------------------ backward
 @pytest.mark.parametrize("cls", ["GCNCheb", "TGCNCheb_H", "ChebConv", "ChebTimeConv"])
 def test_backward_vs_dense_autograd(cls, gpu_device):

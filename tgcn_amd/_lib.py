@@ -48,6 +48,8 @@ SIGNATURES = {
     "tgcn_cheb_project_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P),
                                         C.POINTER(C.c_int64), _P, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                         _P, C.c_int64]),
+    "tgcn_cheb_project_windows_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P), _P, _P,
+                                                C.c_int32, _P]),
     "tgcn_cheb_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "tgcn_cheb_wgrad_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64), _P,
                                       C.c_int64, _P, _P, C.c_size_t]),

@@ -458,7 +458,13 @@ struct ProjParams {
   float* out;
   int64_t M, ldo, n_vertices, interleave;
   int32_t Kc, N, nterms, bias_kind, accumulate, vec_epilogue;
+  int32_t win_n, win_t;   // > 0: row m of A_t is the window starting at A_t[(m / win_n) * win_t + (m % win_n)]
 };
+
+// float offset of row m of a term: plain row stride, or overlapping time windows of a (vertex, T) series
+__device__ __forceinline__ int64_t proj_row_off(const ProjParams& p, int64_t m, int64_t lda) {
+  return p.win_n > 0 ? (m / p.win_n) * p.win_t + (m % p.win_n) : m * lda;
+}
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
           const int row = (tid >> 5) + h * 8, kk = tid & 31;
-          ra[h] = (m0 + row < p.M && k0 + kk < p.Kc) ? A[(m0 + row) * lda + k0 + kk] : 0.f;
+          ra[h] = (m0 + row < p.M && k0 + kk < p.Kc) ? A[proj_row_off(p, m0 + row, lda) + k0 + kk] : 0.f;
         }
       }
       float rw[(KT * NW + kBlock - 1) / kBlock];
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
           const bool ok = (m0 + i < p.M) && (k0 + lane < p.Kc);
           const int64_t rr = (m0 + i < p.M) ? m0 + i : p.M - 1;
           const int kc = (k0 + lane < p.Kc) ? k0 + lane : 0;
-          const float v = A[rr * lda + kc];
+          const float v = A[proj_row_off(p, rr, lda) + kc];
           ra[i][0] = ok ? v : 0.f;
         }
       }
@@ -1190,9 +1196,31 @@ int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, i
   return g.vec == 4 ? launch_hop_vec<4>(st, p, g.lpr, grid, fix_grid) : launch_hop_vec<1>(st, p, g.lpr, grid, fix_grid);
 }
 
+static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
+                        const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
+                        int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
+                        int32_t win_n, int32_t win_t);
+
 int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                           const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                           int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo) {
+  return project_impl(stream, M, Kc, N, nterms, a, lda, W, bias, bias_kind, n_vertices, interleave, accumulate, out, ldo, 0, 0);
+}
+
+int tgcn_cheb_project_windows_f32(void* stream, int64_t n_vertices, int32_t T, int32_t H, int32_t N, int32_t nterms,
+                                  const float* const* series, const float* W, const float* bias, int32_t bias_kind,
+                                  float* out) {
+  if (T < H || H < 1) TGCN_FAIL(TGCN_ERR_INVALID, "project_windows: need 1 <= H <= T");
+  const int32_t nwin = T - H + 1;
+  int64_t lda[kMaxTerms];
+  for (int t = 0; t < kMaxTerms; ++t) lda[t] = T;
+  return project_impl(stream, n_vertices * nwin, H, N, nterms, series, lda, W, bias, bias_kind, n_vertices, nwin, 0, out, N, nwin, T);
+}
+
+static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
+                        const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
+                        int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
+                        int32_t win_n, int32_t win_t) {
   if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "project: bad argument");
   if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "project: bias_kind %d", bias_kind);
@@ -1200,7 +1228,8 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
   if (interleave > 1 && M != interleave * n_vertices) TGCN_FAIL(TGCN_ERR_INVALID, "project: M != interleave*n_vertices");
   ProjParams p;
   memset(&p, 0, sizeof(p));
-  bool vec4 = (Kc % 4 == 0);
+  bool vec4 = (Kc % 4 == 0) && win_n == 0;   // windows start at any float: scalar loads
+  p.win_n = win_n; p.win_t = win_t;
   for (int t = 0; t < nterms; ++t) {
     if (!a[t]) TGCN_FAIL(TGCN_ERR_INVALID, "project: null term %d", t);
     p.a[t] = a[t];

@@ -78,6 +78,33 @@ def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
     return out
 
 
+def cheb_time_windows(op, series, weight_khg, bias, bias_kind, mode=MODE_POWER):
+    """Streaming form of TGCNCheb_H / ChebTimeConv on sliding windows (f = 1): series (S, n, T) raw recordings,
+    weight (K, H, N) in the reference basis.  Returns (S * (T-H+1), n, N), identical to running the layer on the
+    windowed batch x[s*(T-H+1) + w, i, h] = series[s, i, w + h] (load/data_hcp.py:146-152), but the K-1 hops run
+    once on the T columns of each recording.  Inference path (no autograd)."""
+    _lib.require_device(series, weight_khg, bias)
+    L = _lib.lib()
+    S, n, T = series.shape
+    K, H, N = weight_khg.shape
+    nwin = T - H + 1
+    with torch.no_grad():
+        W = weight_khg.float()
+        if mode == MODE_POWER and K > 2:
+            W = torch.einsum("kj,khn->jhn", power_fold_matrix(K, W.device), W)
+        W = W.reshape(K * H, N).contiguous()
+        x3 = series.float().contiguous()
+        stack = _monomial_stack(op, x3, K) if mode == MODE_POWER else cheb_stack(op, x3, K, MODE_CHEBYSHEV)   # (K, S, n, T)
+        out = torch.empty((S * nwin, n, N), dtype=torch.float32, device=series.device)
+        b = bias.contiguous() if bias is not None else None
+        assert K <= 32, "more than 32 hops: chunk the projection"
+        for s in range(S):
+            ptrs = (C.c_void_p * K)(*[stack[k, s].data_ptr() for k in range(K)])
+            _lib.check(L.tgcn_cheb_project_windows_f32(_lib.stream_ptr(), n, T, H, N, K, ptrs, _lib.ptr(W), _lib.ptr(b), bias_kind,
+                                                       _lib.ptr(out[s * nwin:])))
+    return out
+
+
 def cheb_wgrad(terms, g2d):
     """dW[t] = terms[t]^T @ g2d  ->  (T, Kc, N); terms: list of (M, Kc) views with contiguous rows, g2d: (M, N)."""
     _lib.require_device(g2d, *terms)

@@ -134,6 +134,18 @@ class TGCNCheb_H(_DenseLBase):
             X = X.unsqueeze(3)
         return self._stack(X)
 
+    def forward_series(self, series):
+        """Additive API (not in the reference): series (S, n, T) raw recordings -> the layer's output for all
+        T-H+1 sliding windows of every recording, (S*(T-H+1), n, g), without materialising the windows
+        (load/data_hcp.py:116-154 builds them on the host and the hops then run H times too often).
+        in_channels must be 1.  Inference only."""
+        assert self.in_channels == 1, "forward_series: in_channels must be 1"
+        K, H = self.weight.shape[0], self.weight.shape[1]
+        W = self.weight.reshape(K, H, self.out_channels)
+        return F.cheb_time_windows(self._operand(series.device), series, W,
+                                   None if self.bias is None else self.bias.reshape(-1),
+                                   F.BIAS_NONE if self.bias is None else F.BIAS_VERTEX_CHANNEL, F.MODE_POWER)
+
 
 class GCNCheb(_DenseLBase):
     """reference: tgcn/nn/gcn.py:158-237.  x (q, n[, f]) -> (q, n, g); weight (K, f, g); bias (1, 1, g)."""
