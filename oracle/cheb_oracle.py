@@ -44,6 +44,20 @@ def coo_to_csr(row, col, val, n):
     return sp.coo_matrix((val, (row, col)), shape=(n, n)).tocsr()
 
 
+def rescaled_laplacian(W, lmax=2):
+    """gcn/graph.py:117-136 (laplacian, normalized) followed by :232-238 (rescale_L):
+    d = W.sum(axis=0) + spacing(0); L = I - D^-1/2 W D^-1/2; L-hat = L / (lmax/2) - I."""
+    W = sp.csr_matrix(W)
+    d = np.asarray(W.sum(axis=0)).squeeze().astype(W.dtype)
+    d = d + np.spacing(np.array(0, W.dtype))
+    dis = (1 / np.sqrt(d)).astype(W.dtype)
+    D = sp.diags(dis, 0)
+    I = sp.identity(d.size, dtype=W.dtype, format="csr")
+    L = I - D * W * D
+    L = L / (lmax / 2)
+    return (L - I).tocsr()
+
+
 # ----------------------------------------------------------------------------- L x (batched)
 def _apply(L, X):
     """L (n x n, scipy sparse) applied along axis 1 of X (q, n, ...): einsum("nm,qm...->qn...") of

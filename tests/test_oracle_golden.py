@@ -83,6 +83,24 @@ def test_uniform_and_pool():
     assert np.array_equal(O.gcn_pool(g["pool_x"], 4), g["pool4"])
 
 
+@pytest.mark.parametrize("path", golden_files("operand_"), ids=golden_ids(golden_files("operand_")))
+def test_operand_builder(path):
+    """rescale_L(laplacian(A)) : the oracle's restatement and the product's device-side builder (torch index ops,
+    runs on CPU tensors too) against the reference's own output."""
+    import scipy.sparse as sp
+    import torch
+    from tgcn_amd.graph import GraphOperand
+    g = load_golden(path)
+    n = int(g["n"])
+    ref = O.csr_from_arrays(n, g["L_rowptr"], g["L_col"], g["L_val"])
+    A = sp.coo_matrix((g["a_val"], (g["a_row"], g["a_col"])), shape=(n, n)).tocsr()
+    mine = O.rescaled_laplacian(A, float(g["lmax"]))
+    assert abs(mine - ref).max() <= 1e-6
+    op = GraphOperand.from_adjacency(n, torch.as_tensor(g["a_row"]), torch.as_tensor(g["a_col"]), torch.as_tensor(g["a_val"]),
+                                     lmax=float(g["lmax"]))
+    assert abs(op.to_scipy() - ref).max() <= 1e-6
+
+
 # ---------------------------------------------------------------------------- plain-C restatement (CPU baseline)
 def _c_forward(g, mode, x3, W, bias_kind, L=None):
     from oracle import c_port

@@ -182,6 +182,28 @@ class GraphOperand:
         lap = -dis[row] * w * dis[col]
         return GraphOperand.from_coo(n, row, col, lap, device)
 
+    @staticmethod
+    def from_adjacency(n, row, col, weight, lmax=2.0, device=None):
+        """The operand the callers build on the host before every layer -- rescale_L(laplacian(W, normalized=True),
+        lmax) (gcn/graph.py:117-136, 232-238; examples/gcn_mnist.py:131 re-does it every forward) -- from the COO of
+        the weight matrix W, on the device:  d = colsum(W) + eps,  L = I - D^-1/2 W D^-1/2,  L-hat = L * (2/lmax) - I.
+        With lmax = 2 the diagonal cancels and L-hat = -D^-1/2 W D^-1/2."""
+        device = row.device if device is None else torch.device(device)
+        row = row.to(device=device, dtype=torch.int64)
+        col = col.to(device=device, dtype=torch.int64)
+        w = weight.to(device=device, dtype=torch.float32)
+        d = torch.zeros(n, dtype=torch.float32, device=device).index_add_(0, col, w)      # W.sum(axis=0)
+        d = d + 1.401298464324817e-45                                                      # np.spacing(float32(0))
+        dis = 1.0 / torch.sqrt(d)
+        scale = 2.0 / float(lmax)
+        val = -scale * dis[row] * w * dis[col]
+        if scale != 1.0:                                                                   # (2/lmax - 1) on the diagonal
+            diag = torch.arange(n, device=device)
+            row = torch.cat([row, diag])
+            col = torch.cat([col, diag])
+            val = torch.cat([val, torch.full((n,), scale - 1.0, dtype=torch.float32, device=device)])
+        return GraphOperand.from_coo(n, row, col, val, device)
+
     # ------------------------------------------------------------------ derived operands
     def coo(self):
         counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)

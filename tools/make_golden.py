@@ -289,5 +289,15 @@ def main():
          pool2=rgcn.gcn_pool(xp).numpy(), pool4=rgcn.gcn_pool_4(xp).numpy(), third_party_restated=0)
 
 
+    # ------------------------------------------------ graph operand: rescale_L(laplacian(A, normalized=True), lmax)
+    # (gcn/graph.py:117-136, 232-238) -- the step the callers run right before the layer (examples/gcn_mnist.py:131)
+    for gname, Acsr, lm in (("grid784", A_grid, 2), ("dti148", A_dti, 2), ("rmat1024", A_r, 1.5)):
+        Lh = rgraph.rescale_L(rgraph.laplacian(Acsr.astype(np.float32), normalized=True), lmax=lm).tocsr()
+        coo = Acsr.tocoo()
+        save("operand_%s_lmax%s" % (gname, str(lm).replace(".", "p")), kind="operand", lmax=np.float64(lm), n=np.int64(Acsr.shape[0]),
+             a_row=coo.row.astype(np.int64), a_col=coo.col.astype(np.int64), a_val=coo.data.astype(np.float32),
+             third_party_restated=0, **{("L_" + k): v for k, v in csr_arrays(Lh).items() if k != "n"})
+
+
 if __name__ == "__main__":
     main()
