@@ -167,6 +167,18 @@ int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, i
                                 const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
                                 float* out);
 
+/* Fused epilogue of the callers' pattern  x = gcn_pool_4(F.relu(layer(x)))  (examples/pytorch_based/
+ * pytorch_hcp_tgcn.py:134-141): out (q, n/pool, N) = max over `pool` consecutive vertices of
+ * relu(layer output); pool_idx (nullable, uint8) receives the arg-max offset for the backward.
+ * _small_pool: inside the one-launch small-graph kernel (the layer output never reaches HBM);
+ * tgcn_relu_pool_f32 / _bwd: the same epilogue as its own pass for shapes the small-graph kernel does not take. */
+int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
+                                     const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
+                                     int32_t relu, int32_t pool, float* out, uint8_t* pool_idx);
+int tgcn_relu_pool_f32(void* stream, const float* x, float* out, uint8_t* idx, int64_t q, int64_t n, int32_t f, int32_t p);
+int tgcn_relu_pool_bwd_f32(void* stream, const float* grad_z, const float* z, const uint8_t* idx, float* grad_y, int64_t q,
+                           int64_t n, int32_t f, int32_t p);
+
 /* gcn_pool / gcn_pool_4 (gcn.py:246-255): max over p consecutive vertices; idx (nullable) receives the
  * arg-max offset 0..p-1 for the backward. */
 int tgcn_pool_max_f32(void* stream, const float* x, float* out, int32_t* idx, int64_t q, int64_t n, int32_t f,

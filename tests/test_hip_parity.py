@@ -387,6 +387,46 @@ def test_backward_vs_dense_autograd(cls, gpu_device):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy().reshape(a.shape)) <= 2e-5
 
 
+@pytest.mark.parametrize("cls,n,pool", [("TGCNCheb_H", 784, 4), ("GCNCheb", 400, 2), ("ChebConv", 5000, 4), ("GCNCheb64", 2048, 4)])
+def test_fused_relu_pool_matches_unfused(cls, n, pool, gpu_device):
+    """cheb_relu_pool(layer, x) == gcn_pool*(relu(layer(x))) in value and in all gradients (small-graph fused kernel
+    for the first two, layer + one relu/pool pass for the larger ones)."""
+    import tgcn_amd
+    rng = np.random.default_rng(n)
+    row, col, val = _random_graph(n, 5, rng)
+    A = O.coo_to_csr(row, col, np.abs(val), n)
+    A = ((A + A.T) > 0).astype(np.float32)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    coo = A.tocoo()
+    ei = _dev(np.stack([coo.row, coo.col]).astype(np.int64))
+    Lop = tgcn_amd.GraphOperand.from_adjacency(n, _dev(coo.row), _dev(coo.col), _dev(coo.data))
+    torch.manual_seed(0)
+    extra = ()
+    if cls == "TGCNCheb_H":
+        layer, x = tgcn_amd.TGCNCheb_H(Lop, 1, 12, 4, 6).cuda(), torch.randn(3, n, 6, device="cuda")
+    elif cls == "GCNCheb":
+        layer, x = tgcn_amd.GCNCheb(Lop, 3, 10, 5).cuda(), torch.randn(4, n, 3, device="cuda")
+    elif cls == "GCNCheb64":
+        layer, x = tgcn_amd.GCNCheb(Lop, 64, 32, 3).cuda(), torch.randn(2, n, 64, device="cuda")
+    else:
+        layer, x, extra = tgcn_amd.ChebConv(2, 9, 4).cuda(), torch.randn(2, n, 2, device="cuda"), (ei,)
+    x1 = x.clone().requires_grad_(True)
+    z1 = tgcn_amd.cheb_relu_pool(layer, x1, *extra, pool=pool)
+    gz = torch.randn_like(z1)
+    z1.backward(gz)
+    g1 = [x1.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone()]
+    layer.zero_grad()
+    x2 = x.clone().requires_grad_(True)
+    y = torch.relu(layer(x2, *extra))
+    z2 = tgcn_amd.gcn_pool_4(y) if pool == 4 else tgcn_amd.gcn_pool(y)
+    z2.backward(gz)
+    g2 = [x2.grad, layer.weight.grad, layer.bias.grad]
+    assert rel_err(z1.detach().cpu().numpy(), z2.detach().cpu().numpy()) <= TOL
+    for a, b in zip(g1, g2):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+
+
 def test_cpu_tensor_fails_loudly():
     import tgcn_amd
     from tgcn_amd._lib import TgcnError

@@ -62,6 +62,10 @@ SIGNATURES = {
     "tgcn_cheb_forward_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_forward_small_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                               _P, _P, _P, _P, C.c_int32, _P]),
+    "tgcn_cheb_forward_small_pool_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                                   _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "tgcn_relu_pool_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_relu_pool_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_pool_max_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_pool_max_bwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
 }

@@ -846,6 +846,8 @@ struct SmallParams {
   const float* bias;
   float* out;
   int32_t n, nnz, q, K, C, N, mode, bias_kind, dense, spw, npad;   // spw samples per workgroup, npad threads per sample
+  int32_t relu, pool;      // fused epilogue: out = max over `pool` consecutive vertices of relu(layer output)
+  uint8_t* pool_idx;       // (q, n/pool, N) arg-max offset for the backward (nullable)
 };
 
 template <int NTC, int CP>   // CP: input row length padded (registers), C <= CP
@@ -987,6 +989,10 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
 #pragma unroll
         for (int g4 = 0; g4 < NTC / 4; ++g4)
           reinterpret_cast<float4*>(Yn + i * NTC)[g4 ^ swi] = make_float4(acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+      } else if (p.pool > 0) {                        // last step, pooled epilogue: biased row stays in LDS (plain layout)
+        const float* bp = p.bias_kind == 1 ? p.bias + n0 : (p.bias_kind == 2 ? p.bias + (int64_t)i * p.N + n0 : nullptr);
+#pragma unroll
+        for (int g = 0; g < NTC; ++g) Yn[i * NTC + g] = acc[g] + ((bp && n0 + g < p.N) ? bp[g] : 0.f);
       } else {                                        // last step: bias and straight to HBM
         float* o = p.out + ((int64_t)q * n + i) * p.N + n0;
         const float* bp = p.bias_kind == 1 ? p.bias + n0 : (p.bias_kind == 2 ? p.bias + (int64_t)i * p.N + n0 : nullptr);
@@ -1008,6 +1014,24 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
     }
     __syncthreads();
     cur = (cur + 1) % nbuf;
+  }
+  if (p.pool > 0 && live) {   // relu + max over `pool` consecutive vertices (gcn.py:246-255 after F.relu), from LDS
+    const float* Yf = Ybase + ((cur + nbuf - 1) % nbuf) * n * NTC;
+    const int np = n / p.pool;
+    for (int e = li; e < np * NTC; e += p.npad) {
+      const int ip = e / NTC, g = e % NTC;
+      if (n0 + g >= p.N) continue;
+      float best = Yf[(ip * p.pool) * NTC + g];
+      int bi = 0;
+      for (int jj = 1; jj < p.pool; ++jj) {
+        const float v = Yf[(ip * p.pool + jj) * NTC + g];
+        if (v > best || (v != v && best == best)) { best = v; bi = jj; }
+      }
+      if (p.relu) best = best > 0.f ? best : (best != best ? best : 0.f);
+      const int64_t o = ((int64_t)q * np + ip) * p.N + n0 + g;
+      p.out[o] = best;
+      if (p.pool_idx) p.pool_idx[o] = (uint8_t)bi;
+    }
   }
 }
 
@@ -1060,6 +1084,37 @@ __global__ __launch_bounds__(kBlock) void relayout_kernel(const float* __restric
 // --------------------------------------------------------------------------------------------------
 // pooling
 // --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void relu_pool_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           uint8_t* __restrict__ idx, int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;
+    const int c = (int)(o % f);
+    const float* src = x + row * p * f + c;
+    float best = src[0];
+    int bi = 0;
+    for (int j = 1; j < p; ++j) {
+      const float v = src[(int64_t)j * f];
+      if (v > best || (v != v && best == best)) { best = v; bi = j; }
+    }
+    out[o] = best > 0.f ? best : (best != best ? best : 0.f);
+    if (idx) idx[o] = (uint8_t)bi;
+  }
+}
+
+// grad wrt the layer output of max-pool(relu(.)): the pooled gradient goes to the arg-max vertex where z > 0
+__global__ __launch_bounds__(kBlock) void relu_pool_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ z,
+                                                               const uint8_t* __restrict__ idx, float* __restrict__ gy,
+                                                               int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;
+    const int c = (int)(o % f);
+    const int bi = idx[o];
+    const float g = z[o] > 0.f ? gz[o] : 0.f;
+    float* dst = gy + row * p * f + c;
+    for (int j = 0; j < p; ++j) dst[(int64_t)j * f] = (j == bi) ? g : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void pool_max_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           int32_t* __restrict__ idx, int64_t total, int f, int p) {
   for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
@@ -1361,7 +1416,14 @@ int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t
 int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
                                 const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
                                 float* out) {
+  return tgcn_cheb_forward_small_pool_f32(stream, A, mode, K, q, C, N, x, W, fold, bias, bias_kind, 0, 0, out, nullptr);
+}
+
+int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
+                                     const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
+                                     int32_t relu, int32_t pool, float* out, uint8_t* pool_idx) {
   if (!A || !x || !W || !out || K < 1 || q < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bad argument");
+  if (pool < 0 || pool > 255 || (pool > 0 && A->n % pool != 0) || (pool == 0 && relu)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: pool=%d relu=%d n=%lld", pool, relu, (long long)A->n);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bias_kind %d", bias_kind);
   if (fold && mode != 0) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: fold is for mode 0");
   int dense = 0;
@@ -1370,7 +1432,7 @@ int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, i
   if (q > 2147483647LL || (N + ntc - 1) / ntc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: grid too large");
   SmallParams p;
   p.rowptr = A->rowptr; p.ev = A->edges; p.x = x; p.W = W; p.fold = fold; p.bias = bias; p.out = out;
-  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.N = N; p.mode = mode; p.bias_kind = bias_kind; p.dense = dense;
+  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.N = N; p.mode = mode; p.bias_kind = bias_kind; p.dense = dense; p.relu = relu; p.pool = pool; p.pool_idx = pool_idx;
   // samples per workgroup: as many as fit the 1024-thread / 160 KB budget, but keep >= 512 workgroups in the grid
   p.npad = (p.n + 63) / 64 * 64;
   int spw = 1;
@@ -1485,6 +1547,23 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
     for (int i = 0; i < 2 && i < pass; ++i)
       if (hipStreamWaitEvent(main_st, side->proj_done[i], 0) != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "forward: stream join failed");
   }
+  return TGCN_OK;
+}
+
+int tgcn_relu_pool_f32(void* stream, const float* x, float* out, uint8_t* idx, int64_t q, int64_t n, int32_t f, int32_t p) {
+  if (!x || !out || q <= 0 || n <= 0 || f <= 0 || p <= 0 || p > 255 || n % p != 0) TGCN_FAIL(TGCN_ERR_INVALID, "relu_pool: bad argument");
+  const int64_t total = q * (n / p) * f;
+  hipLaunchKernelGGL(relu_pool_kernel, dim3(grid_1d(total)), dim3(kBlock), 0, (hipStream_t)stream, x, out, idx, total, (int)f, (int)p);
+  TGCN_CHECK_LAUNCH("tgcn_relu_pool_f32");
+  return TGCN_OK;
+}
+
+int tgcn_relu_pool_bwd_f32(void* stream, const float* grad_z, const float* z, const uint8_t* idx, float* grad_y, int64_t q,
+                           int64_t n, int32_t f, int32_t p) {
+  if (!grad_z || !z || !idx || !grad_y || q <= 0 || n <= 0 || f <= 0 || p <= 0 || n % p != 0) TGCN_FAIL(TGCN_ERR_INVALID, "relu_pool_bwd: bad argument");
+  const int64_t total = q * (n / p) * f;
+  hipLaunchKernelGGL(relu_pool_bwd_kernel, dim3(grid_1d(total)), dim3(kBlock), 0, (hipStream_t)stream, grad_z, z, idx, grad_y, total, (int)f, (int)p);
+  TGCN_CHECK_LAUNCH("tgcn_relu_pool_bwd_f32");
   return TGCN_OK;
 }
 

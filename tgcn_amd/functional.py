@@ -243,48 +243,8 @@ class ChebLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        """All contractions run in libtgcn_hip.so: the basis is recomputed with the hop kernel, dW is the MFMA
-        weight-gradient kernel, G = g W^T is the projection kernel with the transposed weight, dx is Horner
-        (mode 0) / Clenshaw (mode 1) on L^T with the hop kernel; only the bias reduction is a torch sum."""
         x3, W = ctx.saved_tensors
-        op, mode, fold = ctx.op, ctx.mode, ctx.fold
-        Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W      # the basis the kernels work in
-        K, Crow, N = Wt.shape
-        q, n, _ = x3.shape
-        g = g.contiguous()
-        g2d = g.reshape(q * n, N)
-        gx = gW = gb = None
-        if ctx.needs_input_grad[1]:
-            x3c = x3.contiguous()
-            basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
-            gW = cheb_wgrad([basis[k].reshape(q * n, Crow) for k in range(K)], g2d)
-            if fold is not None:                                          # back to the reference basis
-                gW = torch.einsum("kj,jcn->kcn", fold, gW)
-        if ctx.needs_input_grad[0]:
-            opT = op.transpose()
-            # G[m, k*C + c] = sum_n g[m, n] W[k, c, n]: one projection with the (N, K*C) transposed weight
-            Wcat = Wt.permute(2, 0, 1).reshape(1, N, K * Crow).contiguous()
-            Gall = cheb_project([g2d], Wcat, None, BIAS_NONE, n).view(q, n, K * Crow)
-            G = [Gall[:, :, k * Crow:(k + 1) * Crow] for k in range(K)]        # strided views, rows contiguous
-            if mode == MODE_POWER:                                       # Horner: b = G_j + L^T b
-                b = G[K - 1]
-                for j in range(K - 2, -1, -1):
-                    b = csr_hop(opT, b, z=G[j], alpha=1.0, beta=1.0)
-                gx = b.contiguous()
-            elif K == 1:
-                gx = G[0].contiguous()
-            else:                                                        # Clenshaw on L^T
-                b1 = torch.zeros((q, n, Crow), dtype=torch.float32, device=g.device)
-                b2 = torch.zeros_like(b1)
-                for k in range(K - 1, 0, -1):
-                    t = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0)
-                    t.add_(G[k])
-                    b1, b2 = t, b1
-                gx = csr_hop(opT, b1, z=b2, alpha=1.0, beta=-1.0)
-                gx.add_(G[0])
-        if ctx.bias_shape is not None and ctx.needs_input_grad[2]:
-            gb = g.sum(dim=(0, 1)) if ctx.bias_kind == BIAS_CHANNEL else g.sum(dim=0)
-            gb = gb.reshape(ctx.bias_shape)
+        gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad)
         return gx, gW, gb, None, None, None
 
 
@@ -299,6 +259,98 @@ def _monomial_stack(op, x3, K):
 def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode):
     """Differentiable fused layer; weight_kcn: (K, C, N) in the reference basis."""
     return ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind)
+
+
+def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs):
+    """Gradients of the layer w.r.t. (x3, W, bias).  All contractions run in libtgcn_hip.so: the basis is recomputed
+    with the hop kernel, dW is the MFMA weight-gradient kernel, G = g W^T is the projection kernel with the transposed
+    weight, dx is Horner (mode 0) / Clenshaw (mode 1) on L^T with the hop kernel; only the bias reduction and the
+    K x K fold of the weight gradient are torch ops."""
+    Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W      # the basis the kernels work in
+    K, Crow, N = Wt.shape
+    q, n, _ = x3.shape
+    g = g.contiguous()
+    g2d = g.reshape(q * n, N)
+    gx = gW = gb = None
+    if needs[1]:
+        x3c = x3.contiguous()
+        basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
+        gW = cheb_wgrad([basis[k].reshape(q * n, Crow) for k in range(K)], g2d)
+        if fold is not None:                                          # back to the reference basis
+            gW = torch.einsum("kj,jcn->kcn", fold, gW)
+    if needs[0]:
+        opT = op.transpose()
+        # G[m, k*C + c] = sum_n g[m, n] W[k, c, n]: one projection with the (N, K*C) transposed weight
+        Wcat = Wt.permute(2, 0, 1).reshape(1, N, K * Crow).contiguous()
+        Gall = cheb_project([g2d], Wcat, None, BIAS_NONE, n).view(q, n, K * Crow)
+        G = [Gall[:, :, k * Crow:(k + 1) * Crow] for k in range(K)]        # strided views, rows contiguous
+        if mode == MODE_POWER:                                       # Horner: b = G_j + L^T b
+            b = G[K - 1]
+            for j in range(K - 2, -1, -1):
+                b = csr_hop(opT, b, z=G[j], alpha=1.0, beta=1.0)
+            gx = b.contiguous()
+        elif K == 1:
+            gx = G[0].contiguous()
+        else:                                                        # Clenshaw on L^T
+            b1 = torch.zeros((q, n, Crow), dtype=torch.float32, device=g.device)
+            b2 = torch.zeros_like(b1)
+            for k in range(K - 1, 0, -1):
+                t = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0)
+                t.add_(G[k])
+                b1, b2 = t, b1
+            gx = csr_hop(opT, b1, z=b2, alpha=1.0, beta=-1.0)
+            gx.add_(G[0])
+    if bias_shape is not None and needs[2]:
+        gb = g.sum(dim=(0, 1)) if bias_kind == BIAS_CHANNEL else g.sum(dim=0)
+        gb = gb.reshape(bias_shape)
+    return gx, gW, gb
+
+
+class ChebReluPoolFn(torch.autograd.Function):
+    """z = max over `pool` consecutive vertices of relu(layer(x)): the callers' `gcn_pool_4(F.relu(layer(x)))`
+    (examples/pytorch_based/pytorch_hcp_tgcn.py:134-141) with the epilogue fused -- inside the one-launch kernel on
+    small graphs (the layer output never reaches HBM), as one extra pass otherwise."""
+
+    @staticmethod
+    def forward(ctx, x3, W, bias, op, mode, bias_kind, pool):
+        K, Crow, N = W.shape
+        x3 = x3.contiguous()
+        W = W.contiguous()
+        b = bias.contiguous() if bias is not None else None
+        q, n, _ = x3.shape
+        assert n % pool == 0, "pooling needs n divisible by the pool size"
+        fold = power_fold_matrix(K, W.device) if (mode == MODE_POWER and K > 2) else None
+        z = torch.empty((q, n // pool, N), dtype=torch.float32, device=x3.device)
+        idx = torch.empty((q, n // pool, N), dtype=torch.uint8, device=x3.device)
+        L = _lib.lib()
+        if small_path_tile(op, Crow, mode):
+            _lib.check(L.tgcn_cheb_forward_small_pool_f32(_lib.stream_ptr(), C.byref(op.struct), mode, K, q, Crow, N, _lib.ptr(x3),
+                                                          _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
+                                                          _lib.ptr(z), _lib.ptr(idx)))
+        else:
+            Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W
+            y = cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
+            _lib.check(L.tgcn_relu_pool_f32(_lib.stream_ptr(), _lib.ptr(y), _lib.ptr(z), _lib.ptr(idx), q, n, N, pool))
+        ctx.save_for_backward(x3, W, z, idx)
+        ctx.op, ctx.mode, ctx.bias_kind, ctx.fold, ctx.pool = op, mode, bias_kind, fold, pool
+        ctx.bias_shape = None if bias is None else bias.shape
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x3, W, z, idx = ctx.saved_tensors
+        q, n, _ = x3.shape
+        N = W.shape[2]
+        gy = torch.empty((q, n, N), dtype=torch.float32, device=gz.device)
+        _lib.check(_lib.lib().tgcn_relu_pool_bwd_f32(_lib.stream_ptr(), _lib.ptr(gz.contiguous()), _lib.ptr(z), _lib.ptr(idx),
+                                                     _lib.ptr(gy), q, n, N, ctx.pool))
+        gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, gy, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad)
+        return gx, gW, gb, None, None, None, None
+
+
+def cheb_relu_pool(op, x3, weight_kcn, bias, bias_kind, mode, pool):
+    """Differentiable relu + max-pool fused layer; weight in the reference basis."""
+    return ChebReluPoolFn.apply(x3, weight_kcn, bias, op, mode, bias_kind, pool)
 
 
 # ----------------------------------------------------------------------------------------- pooling

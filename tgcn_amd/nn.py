@@ -95,10 +95,13 @@ class TGCNCheb(_DenseLBase):
             self.register_parameter('bias', None)
         self.reset_parameters()
 
-    def forward(self, x):
+    def _layer_args(self, x):
         x3 = x.float().contiguous()
-        return F.cheb_layer(self._operand(x3.device), x3, self.weight, self.bias,
-                            F.BIAS_NONE if self.bias is None else F.BIAS_VERTEX_CHANNEL, F.MODE_POWER)
+        return (self._operand(x3.device), x3, self.weight, self.bias,
+                F.BIAS_NONE if self.bias is None else F.BIAS_VERTEX_CHANNEL, F.MODE_POWER)
+
+    def forward(self, x):
+        return F.cheb_layer(*self._layer_args(x))
 
     def _time_chebyshev(self, X):
         return self._stack(X)
@@ -120,14 +123,17 @@ class TGCNCheb_H(_DenseLBase):
             self.register_parameter('bias', None)
         self.reset_parameters()
 
-    def forward(self, x):
+    def _layer_args(self, x):
         if x.dim() == 3:
             x = x.unsqueeze(3)
         q, n, h, f = x.shape
         x3 = x.float().reshape(q, n, h * f).contiguous()
         W = self.weight.reshape(self.weight.shape[0], h * f, self.out_channels)
-        return F.cheb_layer(self._operand(x3.device), x3, W, self.bias,
-                            F.BIAS_NONE if self.bias is None else F.BIAS_VERTEX_CHANNEL, F.MODE_POWER)
+        return (self._operand(x3.device), x3, W, self.bias,
+                F.BIAS_NONE if self.bias is None else F.BIAS_VERTEX_CHANNEL, F.MODE_POWER)
+
+    def forward(self, x):
+        return F.cheb_layer(*self._layer_args(x))
 
     def _time_chebyshev(self, X):
         if X.dim() == 3:
@@ -163,12 +169,15 @@ class GCNCheb(_DenseLBase):
             self.register_parameter('bias', None)
         self.reset_parameters()
 
-    def forward(self, x):
+    def _layer_args(self, x):
         if x.dim() == 2:
             x = x.unsqueeze(2)
         x3 = x.float().contiguous()
-        return F.cheb_layer(self._operand(x3.device), x3, self.weight, self.bias,
-                            F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_POWER)
+        return (self._operand(x3.device), x3, self.weight, self.bias,
+                F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_POWER)
+
+    def forward(self, x):
+        return F.cheb_layer(*self._layer_args(x))
 
     def _chebyshev(self, X):
         if X.dim() == 2:
@@ -240,12 +249,15 @@ class ChebConv(_EdgeBase):
             self.register_parameter('bias', None)
         self.reset_parameters()
 
-    def forward(self, x, edge_index, edge_weight=None):
+    def _layer_args(self, x, edge_index, edge_weight=None):
         op = self._operand(x, edge_index, edge_weight)
         if x.dim() < 3:
             x = x.unsqueeze(-1)
-        return F.cheb_layer(op, x.float().contiguous(), self.weight, self.bias,
-                            F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)
+        return (op, x.float().contiguous(), self.weight, self.bias,
+                F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        return F.cheb_layer(*self._layer_args(x, edge_index, edge_weight))
 
 
 class ChebTimeConv(_EdgeBase):
@@ -262,11 +274,22 @@ class ChebTimeConv(_EdgeBase):
             self.register_parameter('bias', None)
         self.reset_parameters()
 
-    def forward(self, x, edge_index, edge_weight=None):
+    def _layer_args(self, x, edge_index, edge_weight=None):
         op = self._operand(x, edge_index, edge_weight)
         if x.dim() < 4:
             x = x.unsqueeze(-1)
         q, n, h, f = x.shape
         W = self.weight.reshape(self.weight.shape[0], h * f, self.out_channels)
-        return F.cheb_layer(op, x.float().reshape(q, n, h * f).contiguous(), W, self.bias,
-                            F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)
+        return (op, x.float().reshape(q, n, h * f).contiguous(), W, self.bias,
+                F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        return F.cheb_layer(*self._layer_args(x, edge_index, edge_weight))
+
+
+# ------------------------------------------------------------------------------------ fused caller pattern
+def cheb_relu_pool(layer, x, *graph_args, pool=4):
+    """gcn_pool_4(F.relu(layer(x, ...)))  (pool=4)  /  gcn_pool(F.relu(layer(x, ...)))  (pool=2)  in one fused op:
+    additive API for the pattern of examples/pytorch_based/pytorch_hcp_tgcn.py:134-141 and pytorch_mnist_gcn.py.
+    `layer` is any of the five modules above; graph_args are ChebConv's (edge_index[, edge_weight])."""
+    return F.cheb_relu_pool(*layer._layer_args(x, *graph_args), pool)
