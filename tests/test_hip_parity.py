@@ -427,6 +427,44 @@ def test_fused_relu_pool_matches_unfused(cls, n, pool, gpu_device):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
 
 
+@pytest.mark.parametrize("shape", ["general", "small"])
+def test_forward_is_hipgraph_capturable(shape, gpu_device):
+    """The layer driver allocates nothing and never synchronises, so one forward can be captured into a hipGraph
+    and replayed on new input."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(5)
+    n, q, Crow, N, K = (3000, 3, 64, 32, 4) if shape == "general" else (500, 6, 12, 16, 5)
+    row, col, val = _random_graph(n, 7, rng, hubs=((1, 200),))
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val * 0.4))
+    W = _dev((rng.standard_normal((K, Crow, N)) / np.sqrt(K * Crow)).astype(np.float32))
+    b = _dev(rng.standard_normal(N).astype(np.float32))
+    x_static = torch.randn(q, n, Crow, device="cuda")
+
+    def run(x):
+        if shape == "small":
+            return F.cheb_forward_small(op, x, W, None, b, 1, F.MODE_CHEBYSHEV)
+        return F.cheb_forward_raw(op, x, W.reshape(K * Crow, N), b, 1, F.MODE_CHEBYSHEV, K, layout=0, q_chunk=1)
+
+    eager = run(x_static).clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(x_static)                                   # warm-up on the side stream (schedules, allocator)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_static = run(x_static)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_static, eager)
+    x2 = torch.randn(q, n, Crow, device="cuda")
+    x_static.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_static, run(x2))
+
+
 def test_cpu_tensor_fails_loudly():
     import tgcn_amd
     from tgcn_amd._lib import TgcnError
