@@ -1,0 +1,73 @@
+"""A model written the way the reference's training scripts write theirs (two Chebyshev layers, ReLU, gcn_pool_4,
+linear head; cf. examples/pytorch_based/pytorch_hcp_tgcn.py:93-155), importing the layers through the compat path,
+trained for a few SGD steps on synthetic data.  GPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _ring_graph(n, extra, rng):
+    """symmetric normalised operand -D^-1/2 A D^-1/2 of a ring with a few chords, as a dense tensor (what the scripts pass)."""
+    A = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for d in (1, 2):
+            A[i, (i + d) % n] = A[(i + d) % n, i] = 1.0
+    for _ in range(extra):
+        a, b = rng.integers(0, n, 2)
+        if a != b:
+            A[a, b] = A[b, a] = 1.0
+    dis = 1.0 / np.sqrt(A.sum(0))
+    return torch.tensor(-(dis[:, None] * A * dis[None, :]), dtype=torch.float32)
+
+
+def test_two_layer_model_trains(gpu_device):
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    try:
+        from tgcn.nn.gcn import GCNCheb, TGCNCheb_H, gcn_pool_4          # the reference's import line, unchanged
+    finally:
+        sys.path.pop(0)
+    rng = np.random.default_rng(0)
+    L0, L2 = _ring_graph(160, 30, rng), _ring_graph(40, 8, rng)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.tgcn1 = TGCNCheb_H(L0, 1, 16, 6, 15)
+            self.gcn2 = GCNCheb(L2, 16, 24, 5)
+            self.fc = nn.Linear(10 * 24, 6)
+
+        def forward(self, x):
+            x = gcn_pool_4(TF.relu(self.tgcn1(x)))
+            x = gcn_pool_4(TF.relu(self.gcn2(x)))
+            return TF.log_softmax(self.fc(x.view(x.shape[0], -1)), dim=1)
+
+    torch.manual_seed(0)
+    net = Net().cuda()
+    assert sorted(net.state_dict()) == ["fc.bias", "fc.weight", "gcn2.bias", "gcn2.weight", "tgcn1.bias", "tgcn1.weight"]
+    x = torch.randn(64, 160, 15, device="cuda")
+    y = (x[:, :40].mean(dim=(1, 2)) > 0).long() + 2 * (x[:, 80:120].mean(dim=(1, 2)) > 0).long()   # 4 learnable classes
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = TF.nll_loss(net(x), y)
+        loss.backward()
+        for p in net.parameters():
+            assert torch.isfinite(p.grad).all()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    # a checkpoint round trip keeps the function (L is a plain attribute and is not part of the state dict)
+    net2 = Net().cuda()
+    net2.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        assert torch.equal(net(x), net2(x))
