@@ -465,6 +465,34 @@ def test_forward_is_hipgraph_capturable(shape, gpu_device):
     assert torch.equal(out_static, run(x2))
 
 
+def test_degenerate_operands(gpu_device):
+    """No stored entries at all, a single vertex, and a graph whose every row is longer than the segment length."""
+    import tgcn_amd
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    # empty operand: L x = 0, so Xt = [x, 0, -x, 0, x] and the layer is x (W_0 - W_2 + W_4) + bias
+    layer = tgcn_amd.GCNCheb(torch.zeros(37, 37), 3, 4, 5).cuda()
+    x = torch.randn(2, 37, 3, device="cuda")
+    ref = torch.einsum("qnf,fg->qng", x, layer.weight[0] - layer.weight[2] + layer.weight[4]) + layer.bias
+    assert rel_err(layer(x).detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+    big = GraphOperand.from_coo(5000, torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), torch.zeros(0), "cuda")
+    y = F.csr_hop(big, torch.randn(1, 5000, 64, device="cuda"))
+    assert float(y.abs().max()) == 0.0
+    # one vertex with a self weight
+    one = tgcn_amd.TGCNCheb(torch.tensor([[0.5]]), 2, 3, 4).cuda()
+    x1 = torch.randn(5, 1, 2, device="cuda")
+    xt = [x1, 0.5 * x1, 2 * 0.25 * x1 - x1, 2 * 0.125 * x1 - 0.5 * x1]
+    ref1 = sum(torch.einsum("qnf,fg->qng", a, one.weight[k]) for k, a in enumerate(xt)) + one.bias
+    assert rel_err(one(x1).detach().cpu().numpy(), ref1.detach().cpu().numpy()) <= TOL
+    # dense 300 x 300 operand through the general path (every row is cut into segments)
+    rng = np.random.default_rng(1)
+    D = (rng.standard_normal((300, 300)) / 17).astype(np.float32)
+    op = GraphOperand.from_dense(torch.tensor(D), "cuda")
+    xs = rng.standard_normal((2, 300, 64)).astype(np.float32)
+    got = F.csr_hop(op, _dev(xs)).cpu().numpy()
+    assert rel_err(got, np.einsum("nm,qmc->qnc", D.astype(np.float64), xs.astype(np.float64))) <= TOL
+
+
 def test_cpu_tensor_fails_loudly():
     import tgcn_amd
     from tgcn_amd._lib import TgcnError
