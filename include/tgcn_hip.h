@@ -112,6 +112,11 @@ int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sche
                      const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Y,
                      const tgcn_dense* P, void* workspace, size_t workspace_bytes);
 
+/* tgcn_csr_hop_f32 with a second addend:  Y = alpha*S + beta*Z + gamma*Z2  (Clenshaw step of the project-first path). */
+int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t nb, int32_t C,
+                      const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Z2, float gamma,
+                      const tgcn_dense* Y, const tgcn_dense* P, void* workspace, size_t workspace_bytes);
+
 /* Stacked-hop dense projection (gcn.py:39,113,194 einsum; :420-431 / :519-527 per-hop matmul):
  *   out[r(m), :] (+)= sum_t A_t[m, 0:Kc] . W[t*Kc:(t+1)*Kc, 0:N] + bias
  * A_t: M x Kc with row stride lda[t]; W: (nterms*Kc) x N contiguous; fp32 MFMA, fp32 accumulate.
@@ -156,6 +161,16 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
                           int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
                           const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
                           void* workspace, size_t workspace_bytes);
+
+/* "Project first" form of the same layer for wide inputs and narrow outputs (N well below C = H*f, e.g.
+ * TGCNCheb_H(L, 1, 32, K, 1200)): Z = x . Wcat for all K terms in ONE projection (Wcat: C x (K*N), column block j =
+ * W_j, folded for mode 0), then the recursion runs on the (q, n, N) results -- Horner  Y_j = Z_j + L Y_{j+1}  for
+ * mode 0, Clenshaw for mode 1 -- so the K-1 hops move N instead of C floats per row.  Same result as
+ * tgcn_cheb_forward_f32 up to fp32 re-association.  `sched` must be the schedule for rows of N floats. */
+size_t tgcn_cheb_forward_pf_workspace_bytes(const tgcn_csr_sched* sched, int32_t K, int64_t q, int64_t n, int32_t N);
+int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t mode, int32_t K, int64_t q,
+                             int64_t n, int32_t C, int32_t N, const float* x, const float* Wcat, const float* bias,
+                             int32_t bias_kind, float* out, void* workspace, size_t workspace_bytes);
 
 /* Small graphs (n <= 1024, C <= 32, CSR + activations fit in 160 KB of LDS -- the reference's own MNIST / coarsened
  * graphs): the whole layer in ONE launch, recursion run on the output side in LDS (Horner for mode 0, Clenshaw for

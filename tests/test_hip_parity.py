@@ -257,6 +257,33 @@ def test_relayout(gpu_device):
         assert torch.equal(out, x.permute(1, 0, 2).contiguous())
 
 
+@pytest.mark.parametrize("n,q,Crow,N,K,kind", [(3000, 2, 200, 32, 5, 2), (1500, 3, 64, 7, 4, 1), (5000, 1, 129, 16, 1, 0), (2000, 2, 96, 48, 6, 2),
+                                               (1200, 2, 40, 5, 2, 1)])
+def test_project_first_path_vs_oracle(n, q, Crow, N, K, kind, gpu_device):
+    """Project-first form (one projection, then Horner / Clenshaw on the (q, n, N) results) against the oracle."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(n + Crow)
+    row, col, val = _random_graph(n, 6, rng, hubs=((3, 500),), isolated=(0, 11))
+    val = val * 0.5
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((q, n, Crow)).astype(np.float32)
+    W = (rng.standard_normal((K, Crow, N)) / np.sqrt(K * Crow)).astype(np.float32)
+    bias = None if kind == 0 else rng.standard_normal(N if kind == 1 else (n, N)).astype(np.float32)
+    for mode in (F.MODE_POWER, F.MODE_CHEBYSHEV):
+        if mode == F.MODE_POWER:      # driver takes the monomial-folded weight: basis is L^j x
+            P = [x.astype(np.float64)]
+            for _ in range(1, K):
+                P.append(O._apply(L.astype(np.float64), P[-1]))
+            basis = np.stack(P)
+        else:
+            basis = O.stack_chebyshev(L.astype(np.float64), x.astype(np.float64), K)
+        ref = np.einsum("kqnc,kcg->qng", basis, W.astype(np.float64)) + (0 if bias is None else bias)
+        out = F.cheb_forward_pf(op, _dev(x), _dev(W), None if bias is None else _dev(bias), kind, mode)
+        assert rel_err(out.cpu().numpy(), ref) <= TOL, mode
+
+
 @pytest.mark.parametrize("layout,q_chunk", [(0, 0), (0, 1), (0, 2), (1, 0)])
 def test_forward_layouts_agree(layout, q_chunk, gpu_device):
     """The layer result must not depend on the internal layout / pass size."""

@@ -45,6 +45,12 @@ SIGNATURES = {
     "tgcn_csr_hop_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
                                    C.POINTER(DenseStruct), C.POINTER(DenseStruct), C.c_float, C.c_float,
                                    C.POINTER(DenseStruct), C.POINTER(DenseStruct), _P, C.c_size_t]),
+    "tgcn_csr_hop2_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
+                                    C.POINTER(DenseStruct), C.POINTER(DenseStruct), C.c_float, C.c_float,
+                                    C.POINTER(DenseStruct), C.c_float, C.POINTER(DenseStruct), C.POINTER(DenseStruct), _P, C.c_size_t]),
+    "tgcn_cheb_forward_pf_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
+    "tgcn_cheb_forward_pf_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32, C.c_int64,
+                                           C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, C.c_size_t]),
     "tgcn_cheb_project_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P),
                                         C.POINTER(C.c_int64), _P, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                         _P, C.c_int64]),

@@ -74,11 +74,12 @@ struct HopParams {
   const int32_t* long_slot;
   const float* X;
   const float* Z;
+  const float* Z2;
   float* Y;
   float* P;
   float* partial;
-  int64_t x_bs, x_ld, z_bs, z_ld, y_bs, y_ld, p_bs, p_ld;
-  float alpha, beta;
+  int64_t x_bs, x_ld, z_bs, z_ld, z2_bs, z2_ld, y_bs, y_ld, p_bs, p_ld;
+  float alpha, beta, gamma;
   int32_t nblk, nseg, nlong, nhuge, row_thresh;
   int32_t C, nb, nchunks, cpad;
 };
@@ -164,6 +165,12 @@ __device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) y[i] = p.alpha * s[i];
+  }
+  if (p.Z2) {   // second addend (Clenshaw step of the project-first path): y += gamma * z2
+    float z2[VEC];
+    load_vec_nt<VEC>(p.Z2 + (int64_t)b * p.z2_bs + (int64_t)r * p.z2_ld + c0, z2);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = fmaf(p.gamma, z2[i], y[i]);
   }
   if (p.Y) {
     if constexpr (NTM & kNtStores) store_vec_nt<VEC>(p.Y + (int64_t)b * p.y_bs + (int64_t)r * p.y_ld + c0, y);
@@ -458,6 +465,7 @@ struct ProjParams {
   float* out;
   int64_t M, ldo, n_vertices, interleave;
   int32_t Kc, N, nterms, bias_kind, accumulate, vec_epilogue;
+  int32_t bias_ld, bias_cols;   // bias row length and number of leading output columns that receive it
   int32_t win_n, win_t;   // > 0: row m of A_t is the window starting at A_t[(m / win_n) * win_t + (m % win_n)]
 };
 
@@ -562,8 +570,8 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
       const int col = n0 + nt * 16 + col_l;
       if (col >= p.N) continue;
       float v = acc[nt][i];
-      if (p.bias_kind == 1) v += p.bias[col];
-      else if (p.bias_kind == 2) v += p.bias[(r % p.n_vertices) * p.N + col];
+      if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+      else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[(r % p.n_vertices) * p.bias_ld + col];
       float* o = p.out + r * p.ldo + col;
       if (p.accumulate) v += *o;
       *o = v;
@@ -714,9 +722,9 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
         const float2 hi = *reinterpret_cast<const float2*>(&my[row * kResAS + seg + 2]);
         float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
         const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
-        if (p.bias_kind) {
+        if (p.bias_kind && col < p.bias_cols) {
           const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.N : 0) + col);
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         }
         float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
@@ -738,8 +746,8 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
             const int col = n0 + nt * 16 + col_l;
             if (col >= p.N) continue;
             float v = acc[r][nt][i];
-            if (p.bias_kind == 1) v += p.bias[col];
-            else if (p.bias_kind == 2) v += p.bias[vert * p.N + col];
+            if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+            else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
             float* o = p.out + orow * p.ldo + col;
             if (p.accumulate) v += *o;
             *o = v;
@@ -1210,13 +1218,19 @@ size_t tgcn_csr_hop_workspace_bytes(const tgcn_csr_sched* sched, int32_t nb, int
 int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
                      const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Y,
                      const tgcn_dense* P, void* workspace, size_t workspace_bytes) {
+  return tgcn_csr_hop2_f32(stream, A, S, nb, C, X, Z, alpha, beta, nullptr, 0.f, Y, P, workspace, workspace_bytes);
+}
+
+int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
+                      const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Z2, float gamma,
+                      const tgcn_dense* Y, const tgcn_dense* P, void* workspace, size_t workspace_bytes) {
   if (!A || !S || !X || !X->ptr) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null operand");
   if ((!Y || !Y->ptr) && (!P || !P->ptr)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: no output");
   if (A->n <= 0 || A->nnz < 0 || A->nnz >= (int64_t)INT32_MAX || A->n >= (int64_t)INT32_MAX)
     TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: n=%lld nnz=%lld outside int32 index range", (long long)A->n, (long long)A->nnz);
   if (nb <= 0 || C <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: nb=%d C=%d", nb, C);
   if (!A->rowptr || (A->nnz > 0 && !A->edges) || !S->blk_row) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null CSR/schedule array");
-  const int al = aligned4(X) && aligned4(Z) && aligned4(Y) && aligned4(P);
+  const int al = aligned4(X) && aligned4(Z) && aligned4(Z2) && aligned4(Y) && aligned4(P);
   const HopGeom g = hop_geom(C, al);
   if (S->lanes_per_row != g.lpr)
     TGCN_FAIL(TGCN_ERR_INVALID, "hop: schedule built for %d lanes/row, C=%d (aligned16=%d) needs %d", S->lanes_per_row, C, al, g.lpr);
@@ -1236,6 +1250,7 @@ int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, i
   p.long_row = S->long_row; p.long_slot = S->long_slot;
   p.X = X->ptr; p.x_bs = X->batch_stride; p.x_ld = X->row_stride;
   if (Z && Z->ptr) { p.Z = Z->ptr; p.z_bs = Z->batch_stride; p.z_ld = Z->row_stride; }
+  if (Z2 && Z2->ptr) { p.Z2 = Z2->ptr; p.z2_bs = Z2->batch_stride; p.z2_ld = Z2->row_stride; p.gamma = gamma; }
   if (Y && Y->ptr) { p.Y = Y->ptr; p.y_bs = Y->batch_stride; p.y_ld = Y->row_stride; }
   if (P && P->ptr) { p.P = P->ptr; p.p_bs = P->batch_stride; p.p_ld = P->row_stride; }
   p.partial = (float*)workspace;
@@ -1254,7 +1269,7 @@ int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, i
 static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
-                        int32_t win_n, int32_t win_t);
+                        int32_t win_n, int32_t win_t, int32_t bias_cols = -1);
 
 int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                           const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
@@ -1275,7 +1290,7 @@ int tgcn_cheb_project_windows_f32(void* stream, int64_t n_vertices, int32_t T, i
 static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
-                        int32_t win_n, int32_t win_t) {
+                        int32_t win_n, int32_t win_t, int32_t bias_cols) {
   if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "project: bad argument");
   if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "project: bias_kind %d", bias_kind);
@@ -1285,6 +1300,8 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   memset(&p, 0, sizeof(p));
   bool vec4 = (Kc % 4 == 0) && win_n == 0;   // windows start at any float: scalar loads
   p.win_n = win_n; p.win_t = win_t;
+  p.bias_cols = bias_cols < 0 ? N : bias_cols;   // bias rows have bias_cols floats
+  p.bias_ld = p.bias_cols;
   for (int t = 0; t < nterms; ++t) {
     if (!a[t]) TGCN_FAIL(TGCN_ERR_INVALID, "project: null term %d", t);
     p.a[t] = a[t];
@@ -1293,7 +1310,8 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   }
   p.W = W; p.bias = bias; p.out = out; p.M = M; p.ldo = ldo; p.n_vertices = n_vertices; p.interleave = interleave;
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.bias_kind = bias_kind; p.accumulate = accumulate;
-  p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+  p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                   (p.bias_cols % 4 == 0);
   const int nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
   hipStream_t st = (hipStream_t)stream;
   const int kc4 = (Kc + 3) / 4 * 4;
@@ -1564,6 +1582,67 @@ int tgcn_relu_pool_bwd_f32(void* stream, const float* grad_z, const float* z, co
   const int64_t total = q * (n / p) * f;
   hipLaunchKernelGGL(relu_pool_bwd_kernel, dim3(grid_1d(total)), dim3(kBlock), 0, (hipStream_t)stream, grad_z, z, idx, grad_y, total, (int)f, (int)p);
   TGCN_CHECK_LAUNCH("tgcn_relu_pool_bwd_f32");
+  return TGCN_OK;
+}
+
+// Workspace of the project-first path: Z (q*n x K*N) + 3 result buffers (q*n x N) + hop scratch.
+static void pf_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t N, size_t* z_bytes, size_t* y_bytes,
+                         size_t* off_part, size_t* total) {
+  *z_bytes = align_up((size_t)q * n * K * N * sizeof(float), 256);
+  *y_bytes = align_up((size_t)q * n * N * sizeof(float), 256);
+  *off_part = *z_bytes + 3 * *y_bytes;
+  *total = *off_part + align_up(tgcn_csr_hop_workspace_bytes(S, (int32_t)q, N, N % 4 == 0), 256);
+}
+
+size_t tgcn_cheb_forward_pf_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t N) {
+  if (!S || K < 1 || q < 1 || n < 1 || N < 1) return 0;
+  size_t a, b, c, t;
+  pf_ws_layout(S, K, q, n, N, &a, &b, &c, &t);
+  return t;
+}
+
+int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t mode, int32_t K, int64_t q,
+                             int64_t n, int32_t C, int32_t N, const float* x, const float* Wcat, const float* bias,
+                             int32_t bias_kind, float* out, void* workspace, size_t workspace_bytes) {
+  if (!A || !S || !x || !Wcat || !out) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pf: null operand");
+  if (K < 1 || q < 1 || n < 1 || C < 1 || N < 1 || n != A->n || q > 65535) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pf: bad shape");
+  if (mode != 0 && mode != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pf: mode %d", mode);
+  size_t z_bytes, y_bytes, off_part, total;
+  pf_ws_layout(S, K, q, n, N, &z_bytes, &y_bytes, &off_part, &total);
+  if (!workspace || workspace_bytes < total || ((uintptr_t)workspace & 15)) TGCN_FAIL(TGCN_ERR_WORKSPACE, "forward_pf: workspace %zu < %zu", workspace_bytes, total);
+  char* ws = (char*)workspace;
+  const int64_t M = q * n, KN = (int64_t)K * N;
+  float* Zb = (K == 1) ? out : (float*)ws;      // K == 1: the projection IS the layer
+  const float* a1[1] = {x};
+  const int64_t lda1[1] = {C};
+  int rc = project_impl(stream, M, C, (int32_t)KN, 1, a1, lda1, Wcat, bias, bias_kind, n, 1, 0, Zb, KN, 0, 0, N);
+  if (rc != TGCN_OK || K == 1) return rc;
+  float* part = (float*)(ws + off_part);
+  const size_t part_bytes = total - off_part;
+  auto zview = [&](int j) { return tgcn_dense{Zb + (int64_t)j * N, n * KN, KN}; };
+  auto ybuf = [&](int i) { return tgcn_dense{(float*)(ws + z_bytes + (size_t)i * y_bytes), n * (int64_t)N, N}; };
+  const tgcn_dense outd = {out, n * (int64_t)N, N};
+  if (mode == 0) {            // Horner: Y_j = Z_j + L Y_{j+1}
+    tgcn_dense cur = zview(K - 1);
+    for (int j = K - 2; j >= 0; --j) {
+      const tgcn_dense zj = zview(j);
+      const tgcn_dense dst = (j == 0) ? outd : ybuf(j & 1);
+      rc = tgcn_csr_hop2_f32(stream, A, S, (int32_t)q, N, &cur, &zj, 1.f, 1.f, nullptr, 0.f, &dst, nullptr, part, part_bytes);
+      if (rc != TGCN_OK) return rc;
+      cur = dst;
+    }
+  } else {                    // Clenshaw: b_k = Z_k + 2 L b_{k+1} - b_{k+2};  out = Z_0 + L b_1 - b_2
+    tgcn_dense b1 = zview(K - 1), b2 = {nullptr, 0, 0};
+    for (int k = K - 2; k >= 0; --k) {
+      const tgcn_dense zk = zview(k);
+      const tgcn_dense dst = (k == 0) ? outd : ybuf(k % 3);
+      rc = tgcn_csr_hop2_f32(stream, A, S, (int32_t)q, N, &b1, b2.ptr ? &b2 : nullptr, k == 0 ? 1.f : 2.f, -1.f, &zk, 1.f, &dst,
+                             nullptr, part, part_bytes);
+      if (rc != TGCN_OK) return rc;
+      b2 = b1;
+      b1 = dst;
+    }
+  }
   return TGCN_OK;
 }
 

@@ -219,6 +219,44 @@ def cheb_forward_small(op, x3, W_kcn, fold, bias, bias_kind, mode):
     return out
 
 
+def cheb_forward_pf(op, x3, Wt_kcn, bias, bias_kind, mode):
+    """Project-first form (tgcn_cheb_forward_pf_f32): ONE projection x . [W_0 | ... | W_{K-1}], then Horner / Clenshaw
+    on the (q, n, N) results.  Wt_kcn: (K, C, N), already folded for MODE_POWER."""
+    _lib.require_device(x3, Wt_kcn, bias)
+    L = _lib.lib()
+    q, n, Crow = x3.shape
+    K, _, N = Wt_kcn.shape
+    Wcat = Wt_kcn.permute(1, 0, 2).reshape(Crow, K * N).contiguous()
+    sched = op.schedule_for(N, N % 4 == 0)
+    ws_bytes = L.tgcn_cheb_forward_pf_workspace_bytes(C.byref(sched.struct), K, q, n, N)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
+    out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
+    _lib.check(L.tgcn_cheb_forward_pf_f32(_lib.stream_ptr(), C.byref(op.struct), C.byref(sched.struct), mode, K, q, n, Crow, N,
+                                          _lib.ptr(x3), _lib.ptr(Wcat), _lib.ptr(bias), bias_kind, _lib.ptr(out), _lib.ptr(ws),
+                                          ws.numel()))
+    return out
+
+
+PROJECT_FIRST = True   # developer switch
+
+
+def use_project_first(q, n, C_row, N):
+    """Hops move N floats per row instead of C: take it when the output is at most half as wide as the input row."""
+    return PROJECT_FIRST and 2 * N <= C_row and q <= 65535
+
+
+def layer_forward(op, x3, W, fold, b, bias_kind, mode):
+    """Forward of the layer on whichever path fits the shape (all in libtgcn_hip.so): the one-launch LDS kernel for
+    small graphs, project-first for wide inputs / narrow outputs, hops-then-projection otherwise."""
+    K, Crow, N = W.shape
+    if small_path_tile(op, Crow, mode):
+        return cheb_forward_small(op, x3, W, fold, b, bias_kind, mode)
+    Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W
+    if use_project_first(x3.shape[0], x3.shape[1], Crow, N):
+        return cheb_forward_pf(op, x3, Wt, b, bias_kind, mode)
+    return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
+
+
 class ChebLayerFn(torch.autograd.Function):
     """out = sum_k T_k x W_k + bias with T_k given by `mode`; x3 (q,n,C), W (K, C, N) in the REFERENCE basis.
     For MODE_POWER the weight is folded to the monomial basis (W'_j = sum_k c[k,j] W_k): inside the kernel on the
@@ -231,11 +269,7 @@ class ChebLayerFn(torch.autograd.Function):
         W = W.contiguous()
         b = bias.contiguous() if bias is not None else None
         fold = power_fold_matrix(K, W.device) if (mode == MODE_POWER and K > 2) else None
-        if small_path_tile(op, Crow, mode):
-            out = cheb_forward_small(op, x3, W, fold, b, bias_kind, mode)
-        else:
-            Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W
-            out = cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
+        out = layer_forward(op, x3, W, fold, b, bias_kind, mode)
         ctx.save_for_backward(x3, W)
         ctx.op, ctx.mode, ctx.bias_kind, ctx.fold = op, mode, bias_kind, fold
         ctx.bias_shape = None if bias is None else bias.shape
@@ -328,8 +362,7 @@ class ChebReluPoolFn(torch.autograd.Function):
                                                           _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
                                                           _lib.ptr(z), _lib.ptr(idx)))
         else:
-            Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W
-            y = cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
+            y = layer_forward(op, x3, W, fold, b, bias_kind, mode)
             _lib.check(L.tgcn_relu_pool_f32(_lib.stream_ptr(), _lib.ptr(y), _lib.ptr(z), _lib.ptr(idx), q, n, N, pool))
         ctx.save_for_backward(x3, W, z, idx)
         ctx.op, ctx.mode, ctx.bias_kind, ctx.fold, ctx.pool = op, mode, bias_kind, fold, pool
