@@ -476,107 +476,127 @@ __device__ __forceinline__ int64_t proj_row_off(const ProjParams& p, int64_t m, 
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// Block = 4 waves, 64 output rows; wave w owns rows [16w,16w+16) x NT*16 columns as NT accumulators of
+// Streaming-W kernel: block = 4 waves, 128 output rows; wave w owns rows [32w,32w+32) x NT*16 columns as 2*NT accumulators of
 // v_mfma_f32_16x16x4_f32 (A[l&15][k=l>>4], B[k=l>>4][l&15], D col=l&15,row=(l>>4)*4+reg).
 // LDS strides: As 34 (== 2 mod 32) and Ws == 16 mod 32 make both fragment reads conflict-free.
 template <int NT, bool VEC4>
 __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
-  constexpr int BM = 64, KT = 32, AS = KT + 2;
+  constexpr int BM = 128, KT = 32, AS = KT + 2;   // 4 waves x 32 rows; wave = two 16-row MFMA tiles sharing B fragments
   constexpr int NW = NT * 16;
   constexpr int NS = (NW % 32 == 0) ? NW + 16 : NW;
+  constexpr int WREG = (KT * NW) / kBlock;
   __shared__ float As[BM * AS];
   __shared__ float Ws[KT * NS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * NW;
-  f32x4 acc[NT];
+  f32x4 acc[2][NT];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = (p.Kc + KT - 1) / KT;
+  const int total = p.nterms * ktiles;
 
-  for (int term = 0; term < p.nterms; ++term) {
+  // software pipeline: tile t+1 travels global -> registers while tile t is multiplied out of LDS
+  float ra[16], rw[WREG];
+  auto load_tile = [&](int ti) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
     const float* __restrict__ A = p.a[term];
     const int64_t lda = p.lda[term];
     const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
-    for (int k0 = 0; k0 < p.Kc; k0 += KT) {
-      // ---- global -> registers
-      float ra[8];
-      if constexpr (VEC4) {
+    if constexpr (VEC4) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (m0 + row < p.M && k0 + kk < p.Kc)
-            v = *reinterpret_cast<const float4*>(A + (m0 + row) * lda + k0 + kk);
-          ra[h * 4 + 0] = v.x; ra[h * 4 + 1] = v.y; ra[h * 4 + 2] = v.z; ra[h * 4 + 3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          const int row = (tid >> 5) + h * 8, kk = tid & 31;
-          ra[h] = (m0 + row < p.M && k0 + kk < p.Kc) ? A[proj_row_off(p, m0 + row, lda) + k0 + kk] : 0.f;
-        }
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
+        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+        ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
       }
-      float rw[(KT * NW + kBlock - 1) / kBlock];
+    } else {
 #pragma unroll
-      for (int h = 0; h < (KT * NW) / kBlock; ++h) {
-        const int idx = tid + h * kBlock;
-        const int kk = idx / NW, cc = idx % NW;
-        rw[h] = (k0 + kk < p.Kc && n0 + cc < p.N) ? Wt[(int64_t)(k0 + kk) * p.N + n0 + cc] : 0.f;
+      for (int h = 0; h < 16; ++h) {
+        const int row = (tid >> 5) + h * 8, kk = tid & 31;
+        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        const float v = A[proj_row_off(p, rr, lda) + kc];
+        ra[h] = ok ? v : 0.f;
       }
-      __syncthreads();  // everyone is done reading the previous tile
-      if constexpr (VEC4) {
+    }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
-          float2* d = reinterpret_cast<float2*>(&As[row * AS + kk]);
-          d[0] = make_float2(ra[h * 4 + 0], ra[h * 4 + 1]);
-          d[1] = make_float2(ra[h * 4 + 2], ra[h * 4 + 3]);
-        }
-      } else {
+    for (int h = 0; h < WREG; ++h) {
+      const int idx = tid + h * kBlock;
+      const int kk = idx / NW, cc = idx % NW;
+      const bool ok = (k0 + kk < p.Kc) && (n0 + cc < p.N);
+      const float v = Wt[(int64_t)(ok ? k0 + kk : 0) * p.N + (ok ? n0 + cc : 0)];
+      rw[h] = ok ? v : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+    if constexpr (VEC4) {
 #pragma unroll
-        for (int h = 0; h < 8; ++h) As[((tid >> 5) + h * 8) * AS + (tid & 31)] = ra[h];
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
+        float2* d = reinterpret_cast<float2*>(&As[row * AS + kk]);
+        d[0] = make_float2(ra[h * 4 + 0], ra[h * 4 + 1]);
+        d[1] = make_float2(ra[h * 4 + 2], ra[h * 4 + 3]);
       }
+    } else {
 #pragma unroll
-      for (int h = 0; h < (KT * NW) / kBlock; ++h) {
-        const int idx = tid + h * kBlock;
-        Ws[(idx / NW) * NS + (idx % NW)] = rw[h];
-      }
-      __syncthreads();
-      // ---- MFMA over the tile
-      const int kend = min(KT, p.Kc - k0);
-      const float* arow = &As[(wave * 16 + (lane & 15)) * AS + (lane >> 4)];
-      const float* brow = &Ws[(lane >> 4) * NS + (lane & 15)];
+      for (int h = 0; h < 16; ++h) As[((tid >> 5) + h * 8) * AS + (tid & 31)] = ra[h];
+    }
 #pragma unroll
-      for (int ks = 0; ks < KT / 4; ++ks) {
-        if (ks * 4 >= kend) break;
-        const float a = arow[ks * 4];
+    for (int h = 0; h < WREG; ++h) {
+      const int idx = tid + h * kBlock;
+      Ws[(idx / NW) * NS + (idx % NW)] = rw[h];
+    }
+  };
+
+  load_tile(0);
+  const float* arow = &As[(wave * 32 + (lane & 15)) * AS + (lane >> 4)];
+  const float* brow = &Ws[(lane >> 4) * NS + (lane & 15)];
+  for (int ti = 0; ti < total; ++ti) {
+    __syncthreads();   // everyone is done reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (ti + 1 < total) load_tile(ti + 1);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float bv = brow[ks * 4 * NS + nt * 16];
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[nt], 0, 0, 0);
-        }
+    for (int ks = 0; ks < KT / 4; ++ks) {   // K tail: the staged tile is zero-padded
+      const float a0 = arow[ks * 4];
+      const float a1 = arow[16 * AS + ks * 4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = brow[ks * 4 * NS + nt * 16];
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nt], 0, 0, 0);
       }
     }
   }
   // ---- epilogue: bias, row map, store
   const int col_l = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wave * 16 + (lane >> 4) * 4 + i;
-    if (m >= p.M) continue;
-    const int64_t r = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+  for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = n0 + nt * 16 + col_l;
-      if (col >= p.N) continue;
-      float v = acc[nt][i];
-      if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
-      else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[(r % p.n_vertices) * p.bias_ld + col];
-      float* o = p.out + r * p.ldo + col;
-      if (p.accumulate) v += *o;
-      *o = v;
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wave * 32 + r * 16 + (lane >> 4) * 4 + i;
+      if (m >= p.M) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + col_l;
+        if (col >= p.N) continue;
+        float v = acc[r][nt][i];
+        if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+        else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+        float* o = p.out + orow * p.ldo + col;
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
     }
-  }
 }
 
 // W-resident variant for the common case where the whole folded weight fits in LDS (nterms*Kc*N*4 <= 80 KB).
@@ -1341,7 +1361,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (resident)");
     return TGCN_OK;
   }
-  const int64_t mb = (M + 63) / 64;
+  const int64_t mb = (M + 127) / 128;
   if (mb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
   const dim3 grid((unsigned)mb, gy);
   ProfScope ps(TGCN_PROF_PROJECT, st);
