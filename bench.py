@@ -205,6 +205,9 @@ def main():
     fix_ms = [ms for kind, ms in prof if kind == 1]
     C_row = H * spec["f"]
     F = q * C_row
+    pf_path = (not vertex_mode) and hop_ms and _F.use_project_first(q, op.n, C_row, spec["g"]) and not _F.small_path_tile(op, C_row, 0)
+    if pf_path:
+        F = q * spec["g"]      # project-first: the hops run on the (q, n, C_out) results, not on the C_in*H-wide inputs
     nnz_l, n_l = (sh.op.nnz, sh.owned) if vertex_mode else (op.nnz, op.n)      # what ONE rank's launches process
     bytes_recursion = (K - 1) * (8 * nnz_l + 4 * (n_l + 1) + 8 * n_l * F)
     n_hop_launches = len(hop_ms) // args.steps if hop_ms else 0
@@ -233,6 +236,7 @@ def main():
         roofline = dict(bound="hbm", kernel="hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
                         algorithmic_bytes_per_launch=int(bytes_per_launch), launches_per_step=n_hop_launches,
+                        path="project-first (hops on C_out-wide rows)" if pf_path else "hops-first",
                         mean_launch_ms=round(mean_ms, 4), hop_ms_per_step=round(float(np.sum(hop_ms)) / args.steps, 3),
                         fixup_ms_per_step=round(float(np.sum(fix_ms)) / args.steps, 3),
                         project_ms_per_step=round(float(np.sum(proj_ms)) / args.steps, 3))
