@@ -1363,12 +1363,28 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   }
   const int64_t mb = (M + 127) / 128;
   if (mb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
-  const dim3 grid((unsigned)mb, gy);
+  // streaming-W kernel: widest column tile that keeps padding low, so A is read once per block and no MFMA works
+  // on padding (N = 160 -> one block of 10 tiles instead of three of 4)
+  const int tiles = (N + 15) / 16;
+  int nts = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : tiles <= 6 ? 6 : tiles <= 8 ? 8 : 10;
+  if (tiles > 10) {   // several column blocks: the width with the least padded tiles
+    int best = 10, waste = (10 - tiles % 10) % 10;
+    for (int c : {8, 6, 4}) { const int w = (c - tiles % c) % c; if (w < waste) { waste = w; best = c; } }
+    nts = best;
+  }
+  const dim3 grid((unsigned)mb, (unsigned)((tiles + nts - 1) / nts));
   ProfScope ps(TGCN_PROF_PROJECT, st);
 #define TGCN_PROJ(NTV)                                                                               \
   if (vec4) hipLaunchKernelGGL((project_kernel<NTV, true>), grid, dim3(kBlock), 0, st, p);             \
   else hipLaunchKernelGGL((project_kernel<NTV, false>), grid, dim3(kBlock), 0, st, p);
-  if (nt == 1) { TGCN_PROJ(1) } else if (nt == 2) { TGCN_PROJ(2) } else { TGCN_PROJ(4) }
+  switch (nts) {
+    case 1: TGCN_PROJ(1) break;
+    case 2: TGCN_PROJ(2) break;
+    case 4: TGCN_PROJ(4) break;
+    case 6: TGCN_PROJ(6) break;
+    case 8: TGCN_PROJ(8) break;
+    default: TGCN_PROJ(10) break;
+  }
 #undef TGCN_PROJ
   TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32");
   return TGCN_OK;
