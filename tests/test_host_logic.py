@@ -135,6 +135,17 @@ def test_bad_arguments_return_error_codes_not_crashes():
     assert L.tgcn_set_tuning(b"nope", 1) == -1
 
 
+def test_operand_rejects_out_of_range_indices():
+    from tgcn_amd.graph import GraphOperand
+    from tgcn_amd._lib import TgcnError
+    with pytest.raises(TgcnError):
+        GraphOperand.from_coo(4, torch.tensor([0, 1]), torch.tensor([1, 4]), torch.tensor([1.0, 1.0]))
+    with pytest.raises(TgcnError):
+        GraphOperand.from_coo(4, torch.tensor([0, -1]), torch.tensor([1, 2]), torch.tensor([1.0, 1.0]))
+    with pytest.raises(TgcnError):
+        GraphOperand.from_edge_index(torch.tensor([[0, 1], [1, 7]]), None, 4)
+
+
 def test_modules_refuse_cpu_tensors():
     import tgcn_amd
     from tgcn_amd._lib import TgcnError

@@ -22,6 +22,12 @@ def _as_i32(t):
     return t.to(torch.int32).contiguous()
 
 
+def _check_range(row, col, n, ncol):
+    """One-off range check: an out-of-range vertex index would be an out-of-bounds read inside the kernels."""
+    if row.numel() and (int(row.min()) < 0 or int(row.max()) >= n or int(col.min()) < 0 or int(col.max()) >= ncol):
+        raise _lib.TgcnError("graph operand: vertex index outside [0, %d) x [0, %d)" % (n, ncol))
+
+
 class Schedule:
     """Work schedule for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
 
@@ -127,6 +133,9 @@ class GraphOperand:
         row = row.to(device=device, dtype=torch.int64)
         col = col.to(device=device, dtype=torch.int64)
         val = val.to(device=device, dtype=torch.float32)
+        _check_range(row, col, n, n if n_cols is None else n_cols)
+        if not (row.numel() == col.numel() == val.numel()):
+            raise _lib.TgcnError("graph operand: row / col / val lengths differ")
         order = torch.argsort(row * (n if n_cols is None else max(n, n_cols)) + col)
         counts = torch.bincount(row, minlength=n)
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
@@ -170,6 +179,7 @@ class GraphOperand:
         deg^-1/2 = 0 for isolated vertices."""
         device = edge_index.device if device is None else torch.device(device)
         row, col = edge_index[0].to(device), edge_index[1].to(device)
+        _check_range(row, col, n, n)
         keep = row != col
         row, col = row[keep], col[keep]
         if edge_weight is None:
@@ -192,6 +202,7 @@ class GraphOperand:
         row = row.to(device=device, dtype=torch.int64)
         col = col.to(device=device, dtype=torch.int64)
         w = weight.to(device=device, dtype=torch.float32)
+        _check_range(row, col, n, n)
         d = torch.zeros(n, dtype=torch.float32, device=device).index_add_(0, col, w)      # W.sum(axis=0)
         d = d + 1.401298464324817e-45                                                      # np.spacing(float32(0))
         dis = 1.0 / torch.sqrt(d)
