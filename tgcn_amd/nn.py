@@ -56,7 +56,9 @@ class _DenseLBase(torch.nn.Module):
 
     def _operand(self, device):
         L = self.L
-        key = (id(L), getattr(L, "_version", 0), str(device))
+        dense = isinstance(L, torch.Tensor) and L.layout == torch.strided
+        key = (id(L), L.data_ptr() if dense else None, getattr(L, "_version", 0), tuple(L.shape) if hasattr(L, "shape") else None,
+               str(device))
         return self._ops.get(key, lambda: GraphOperand.from_any(L, device))
 
     def _num_vertices(self):
