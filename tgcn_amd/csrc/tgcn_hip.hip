@@ -605,11 +605,10 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
 // with the next piece's global loads issued before the current piece's MFMAs.  No block barrier in the loop.
 // W image: [term][k padded to 4][NT*16 columns], odd k rows have their 16-column halves swapped when the row
 // is a multiple of 32 floats, so the B-fragment read (k, k+1 in one 32-lane group) is conflict-free.
-constexpr int kResThreads = 512;
-constexpr int kResWaves = kResThreads / 64;
+constexpr int kResMaxThreads = 1024;
 constexpr int kResKT = 64;             // floats of K per staged piece
 constexpr int kResAS = kResKT + 2;     // scratch row stride (== 2 mod 32)
-constexpr int kResRows = 32;           // rows per wave tile (two 16-row MFMA tiles)
+constexpr int kResScratchFloats = 8 * 32 * kResAS;   // wave-private A scratch in total: (512*2/RT threads / 64) waves x 16*RT rows
 constexpr int kResMaxWBytes = 80 * 1024;
 
 template <int NT>
@@ -618,8 +617,11 @@ __device__ __forceinline__ int w_col(int k, int n) {
   else return n;
 }
 
-template <int NT, bool VEC4>
-__global__ __launch_bounds__(kResThreads) void project_resident_kernel(const ProjParams p, const int kc4, const int64_t ntiles) {
+// RT = 16-row MFMA tiles per wave: 2 -> 8 waves x 32 rows (B fragments shared by two tiles), 1 -> 16 waves x 16 rows
+// (4 waves per SIMD to cover LDS / global latency).
+template <int NT, bool VEC4, int RT>
+__global__ __launch_bounds__(1024 / RT) void project_resident_kernel(const ProjParams p, const int kc4, const int64_t ntiles) {
+  constexpr int kResThreads = 1024 / RT, kResWaves = kResThreads / 64, kResRows = 16 * RT;
   extern __shared__ __align__(16) float smem[];
   constexpr int NW = NT * 16;
   float* Ws = smem;                                         // [nterms*kc4][NW]
@@ -642,21 +644,22 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
 
   for (int64_t tile = (int64_t)blockIdx.x * kResWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kResWaves) {
     const int64_t m0 = tile * kResRows;
-    f32x4 acc[2][NT];
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float ra[VEC4 ? 8 : 32][VEC4 ? 4 : 1];
+    constexpr int NRA = VEC4 ? 4 * RT : kResRows, NVA = VEC4 ? 4 : 1;
+    float raA[NRA][NVA], raB[NRA][NVA];   // two pieces in flight (global -> registers) ahead of the one being multiplied
     // loads are unconditional (clamped address, value masked afterwards): no branch per load
-    auto load_piece = [&](int pc) {
+    auto load_piece = [&](int pc, float (&ra)[NRA][NVA]) {
       const int term = pc / npieces, k0 = (pc % npieces) * kResKT;
       const float* __restrict__ A = p.a[term];
       const int64_t lda = p.lda[term];
       if constexpr (VEC4) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * RT; ++i) {
           const int idx = lane + 64 * i, row = idx >> 4, kk = (idx & 15) * 4;
           const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
           const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < kResRows; ++i) {
           const bool ok = (m0 + i < p.M) && (k0 + lane < p.Kc);
           const int64_t rr = (m0 + i < p.M) ? m0 + i : p.M - 1;
           const int kc = (k0 + lane < p.Kc) ? k0 + lane : 0;
@@ -675,10 +678,10 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
         }
       }
     };
-    auto store_piece = [&]() {
+    auto store_piece = [&](const float (&ra)[NRA][NVA]) {
       if constexpr (VEC4) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * RT; ++i) {
           const int idx = lane + 64 * i, row = idx >> 4, kk = (idx & 15) * 4;
           float2* d = reinterpret_cast<float2*>(&my[row * kResAS + kk]);
           d[0] = make_float2(ra[i][0], ra[i][1]);
@@ -686,27 +689,25 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) my[i * kResAS + lane] = ra[i][0];
+        for (int i = 0; i < kResRows; ++i) my[i * kResAS + lane] = ra[i][0];
       }
     };
     const float* a0 = &my[(lane & 15) * kResAS + (lane >> 4)];
     // w_even / w_odd: this lane's row of the W image with the (lane-constant) column swizzle of even / odd
     // column tiles folded in: (nt*16 + c) ^ sw == nt*16 + c + (nt even ? sw : -sw)
     auto kstep = [&](int ks, const float* w_even, const float* w_odd) {
-      const float av0 = a0[ks * 4];
-      const float av1 = a0[16 * kResAS + ks * 4];
+      float av[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) av[r] = a0[r * 16 * kResAS + ks * 4];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const float bv = ((nt & 1) ? w_odd : w_even)[ks * 4 * NW + nt * 16];
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv, acc[1][nt], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv, acc[r][nt], 0, 0, 0);
       }
     };
 
-    load_piece(0);
-    for (int pc = 0; pc < total_pieces; ++pc) {
-      store_piece();                       // previous piece's fragment reads were issued before (in-order LDS)
-      if (pc + 1 < total_pieces) load_piece(pc + 1);
+    auto compute_piece = [&](int pc) {
       const int term = pc / npieces, k0 = (pc % npieces) * kResKT;
       const int ksteps = (min(kResKT, p.Kc - k0) + 3) >> 2;
       const int kbase = term * kc4 + k0 + (lane >> 4);
@@ -720,12 +721,24 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
       } else {
         for (int ks = 0; ks < ksteps; ++ks) kstep(ks, w_even, w_odd);
       }
+    };
+    load_piece(0, raA);
+    if (total_pieces > 1) load_piece(1, raB);
+    for (int pc = 0; pc < total_pieces; pc += 2) {
+      store_piece(raA);                    // previous piece's fragment reads were issued before (in-order LDS)
+      if (pc + 2 < total_pieces) load_piece(pc + 2, raA);
+      compute_piece(pc);
+      if (pc + 1 < total_pieces) {
+        store_piece(raB);
+        if (pc + 3 < total_pieces) load_piece(pc + 3, raB);
+        compute_piece(pc + 1);
+      }
     }
     // ---- epilogue
     if (p.vec_epilogue) {
       // accumulators -> wave scratch (row-major) -> float4 rows: coalesced bias loads and 16-byte stores
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(kResThreads) void project_resident_kernel(const Pro
     } else {
       const int col_l = lane & 15;
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int64_t m = m0 + r * 16 + (lane >> 4) * 4 + i;
@@ -1338,9 +1351,11 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   const size_t wbytes = (size_t)nterms * kc4 * nt * 16 * sizeof(float);
   const unsigned gy = (unsigned)((N + nt * 16 - 1) / (nt * 16));
   if (wbytes <= (size_t)kResMaxWBytes && g_proj_variant.load() != 1) {
-    const size_t lds = wbytes + (size_t)kResWaves * kResRows * kResAS * sizeof(float);
-    const int64_t ntiles = (M + kResRows - 1) / kResRows;
-    int64_t gx = (ntiles + kResWaves - 1) / kResWaves;
+    const int rt = g_proj_variant.load() == 2 ? 1 : 2;                  // 8 waves x 32 rows (variant 2: 16 waves x 16 rows)
+    const int res_rows = 16 * rt, res_waves = 1024 / rt / 64;
+    const size_t lds = wbytes + (size_t)kResScratchFloats * sizeof(float);
+    const int64_t ntiles = (M + res_rows - 1) / res_rows;
+    int64_t gx = (ntiles + res_waves - 1) / res_waves;
     if (gx > 256) gx = 256;    // one persistent workgroup per CU (LDS-limited residency)
     const dim3 grid((unsigned)gx, gy);
     ProfScope ps(TGCN_PROF_PROJECT, st);
@@ -1348,11 +1363,14 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   {                                                                                                           \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
-      hipFuncSetAttribute((const void*)project_resident_kernel<NTV, V4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          kResMaxWBytes + kResWaves * kResRows * kResAS * (int)sizeof(float));                \
+      hipFuncSetAttribute((const void*)project_resident_kernel<NTV, V4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          kResMaxWBytes + kResScratchFloats * (int)sizeof(float));                            \
+      hipFuncSetAttribute((const void*)project_resident_kernel<NTV, V4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          kResMaxWBytes + kResScratchFloats * (int)sizeof(float));                            \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    hipLaunchKernelGGL((project_resident_kernel<NTV, V4>), grid, dim3(kResThreads), lds, st, p, kc4, ntiles); \
+    if (rt == 1) hipLaunchKernelGGL((project_resident_kernel<NTV, V4, 1>), grid, dim3(1024), lds, st, p, kc4, ntiles); \
+    else hipLaunchKernelGGL((project_resident_kernel<NTV, V4, 2>), grid, dim3(512), lds, st, p, kc4, ntiles);          \
   }
     if (nt == 1) { if (vec4) TGCN_PROJ_R(1, true) else TGCN_PROJ_R(1, false) }
     else if (nt == 2) { if (vec4) TGCN_PROJ_R(2, true) else TGCN_PROJ_R(2, false) }
@@ -1453,7 +1471,9 @@ static void fwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t
   *off_xt = o;
   if (layout == 1) o += align_up((size_t)q * n * C * sizeof(float), 256);
   *off_hops = o;
-  *hop_bytes = align_up((size_t)qc * n * C * sizeof(float), 256);
+  // consecutive hop tensors are staggered by an odd multiple of 256 B on top of their size: the projection streams
+  // all K of them at once and equally aligned streams collide on the same DRAM channels (measured: -6 %)
+  *hop_bytes = align_up((size_t)qc * n * C * sizeof(float), 256) + 65 * 256;
   o += (size_t)fwd_nsets(q, qc, layout) * (size_t)(K > 1 ? K - 1 : 0) * *hop_bytes;
   *off_part = o;
   const int32_t nb = layout == 1 ? 1 : (int32_t)qc;

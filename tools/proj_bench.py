@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the projection kernel on the cfg5 shape (developer tool).
-   modes: real = 5 distinct (M,64) terms; alias = 5 x the same term; lda0 = every row reads row 0 (compute only)."""
+   variants: 0 = W-resident 16 waves x 16 rows, 2 = W-resident 8 waves x 32 rows, 1 = streaming-W.  modes: real = 5 distinct (M,64) terms; alias = 5 x the same term; lda0 = every row reads row 0 (compute only)."""
 import ctypes as C
 import os
 import sys
@@ -14,10 +14,14 @@ from tgcn_amd import _lib  # noqa: E402
 def run(M, Kc, N, T, mode, variant, rounds=5):
     L = _lib.lib()
     dev = torch.device("cuda:0")
-    terms = [torch.randn(M, Kc, device=dev) for _ in range(T if mode == "real" else 1)]
+    if mode == "skew":      # 5 distinct terms carved from one buffer with different sub-page offsets (DRAM channel skew)
+        big = torch.randn(T * (M * Kc + 65536 * 4), device=dev)
+        terms = [big[t * (M * Kc + 65536 * 4) + t * 4160: t * (M * Kc + 65536 * 4) + t * 4160 + M * Kc].view(M, Kc) for t in range(T)]
+    else:
+        terms = [torch.randn(M, Kc, device=dev) for _ in range(T if mode == "real" else 1)]
     W = torch.randn(T * Kc, N, device=dev) / (T * Kc) ** 0.5
     out = torch.empty(M, N, device=dev)
-    a = (C.c_void_p * T)(*[terms[i if mode == "real" else 0].data_ptr() for i in range(T)])
+    a = (C.c_void_p * T)(*[terms[i if mode in ("real", "skew") else 0].data_ptr() for i in range(T)])
     lda = (C.c_int64 * T)(*[0 if mode == "lda0" else Kc for _ in range(T)])
     _lib.check(L.tgcn_set_tuning(b"project_variant", variant))
     ts = []
@@ -35,6 +39,6 @@ def run(M, Kc, N, T, mode, variant, rounds=5):
 
 if __name__ == "__main__":
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-    for mode in ("real", "alias", "lda0"):
+    for mode in ("real", "skew", "alias"):
         for variant in (0, 1):
             run(M, 64, 64, 5, mode, variant)
