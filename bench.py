@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--shard", default="time", choices=["time", "vertex"], help="N > 1: time steps per rank (no collective, weak scaling) or vertex rows per rank with a halo / all-gather exchange per hop (strong scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--project-variant", type=int, default=None, help="developer: tgcn_set_tuning(project_variant, v)")
     ap.add_argument("--no-small-path", action="store_true", help="developer: disable the one-launch small-graph kernel")
     args = ap.parse_args()
 
@@ -146,6 +147,8 @@ def main():
     from tgcn_amd import _lib, functional as _F
     if args.no_small_path:
         _F.SMALL_PATH = False
+    if args.project_variant is not None:
+        _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", args.project_variant))
     op, spec = build_workload(args.workload, args.labeling, device, args.vertices, args.entries)
     K, q, H = spec["K"], spec["q"], spec["H"]
     vertex_mode = world > 1 and args.shard == "vertex"

@@ -599,6 +599,223 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
     }
 }
 
+// ---- bf16x3 variant of the streaming-W kernel: fp32-accurate products on the bf16 matrix pipe (16x the fp32 MFMA
+// rate).  Every fp32 operand is split into three bf16 terms a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1),
+// a3 = bf16(a - a1 - a2): 24 mantissa bits in all, the subtractions are exact) and the product is summed as
+// a3w1 + a2w2 + a1w3 + a2w1 + a1w2 + a1w1 with v_mfma_f32_16x16x32_bf16 in fp32 accumulators; the three dropped
+// cross terms are below 2^-24 of |a w|.  6 bf16 MFMAs replace 8 fp32 ones per 32 k at 1/2 the cycles each.
+// Operand maps (gfx950): A[row = l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4) + j][col = l&15], j = 0..7; C/D as fp32.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const bf16x2 h = {(__bf16)a, (__bf16)b};                    // v_cvt_pk_bf16_f32, round to nearest even
+  const unsigned hu = __builtin_bit_cast(unsigned, h);
+  const float ra = a - __uint_as_float(hu << 16), rb = b - __uint_as_float(hu & 0xFFFF0000u);
+  const bf16x2 m = {(__bf16)ra, (__bf16)rb};
+  const unsigned mu = __builtin_bit_cast(unsigned, m);
+  const float sa = ra - __uint_as_float(mu << 16), sb = rb - __uint_as_float(mu & 0xFFFF0000u);
+  const bf16x2 l = {(__bf16)sa, (__bf16)sb};
+  p1 = hu; p2 = mu; p3 = __builtin_bit_cast(unsigned, l);
+}
+
+// Swizzle of the four 16-byte chunks (8 k each) of a 64-byte LDS row: chunk c of row r lives at c ^ G[(r >> 2) & 3],
+// G = {0,2,3,1}.  With ds_read_b128's lane groups ({0-3,12-15,20-27}, ...) the 16 fragment reads of a group then fall
+// on 16 different 16-byte slots of the 256-byte bank row, and ds_write_b64 of whole rows is conflict-free too.
+__device__ __forceinline__ int x3_chunk(int r, int c) { return c ^ ((0x1320 >> (((r >> 2) & 3) * 4)) & 3); }
+
+template <int NT, bool VEC4>
+__global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
+  constexpr int XT = 512;                          // 8 waves x 32 rows: one W tile (and its split) serves 256 rows
+  constexpr int BM = 256, KT = 32, RS = KT;       // LDS rows of 32 bf16 (64 B), 16-byte chunks XOR-swizzled (x3_chunk)
+  constexpr int NW = NT * 16;
+  constexpr int WPAIRS = (KT / 2 * NW + XT - 1) / XT;  // (k, k+1) pairs of one column per thread
+  __shared__ __align__(16) unsigned short Ap[3][BM * RS];
+  __shared__ __align__(16) unsigned short Wp[3][NW * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * NW;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = (p.Kc + KT - 1) / KT;
+  const int total = p.nterms * ktiles;
+
+  float ra[16], rw[2 * WPAIRS];
+  auto load_tile = [&](int ti) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
+    const float* __restrict__ A = p.a[term];
+    const int64_t lda = p.lda[term];
+    const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 64, kk = (tid & 7) * 4;
+        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+        ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
+      }
+    } else {      // thread = (row, k pair)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int row = (tid >> 4) + h * 32, kk = (tid & 15) * 2;
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = (m0 + row < p.M) && (k0 + kk + j < p.Kc);
+          const float v = A[proj_row_off(p, rr, lda) + (ok ? k0 + kk + j : 0)];
+          ra[h * 2 + j] = ok ? v : 0.f;
+        }
+      }
+    }
+    {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        const int idx = min(tid + h * XT, KT / 2 * NW - 1);
+        const int cc = idx % NW, kk = (idx / NW) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = (k0 + kk + j < p.Kc) && (n0 + cc < p.N);
+          const float v = Wt[(int64_t)(ok ? k0 + kk + j : 0) * p.N + (ok ? n0 + cc : 0)];
+          rw[h * 2 + j] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+  auto store_tile = [&]() {      // split into the three bf16 planes on the way into LDS
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 64, kk = (tid & 7) * 4;
+        unsigned a1, a2, a3, b1, b2, b3;
+        split3(ra[h * 4 + 0], ra[h * 4 + 1], a1, a2, a3);
+        split3(ra[h * 4 + 2], ra[h * 4 + 3], b1, b2, b3);
+        const int o = row * RS + x3_chunk(row, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<uint2*>(&Ap[0][o]) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(&Ap[1][o]) = make_uint2(a2, b2);
+        *reinterpret_cast<uint2*>(&Ap[2][o]) = make_uint2(a3, b3);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int row = (tid >> 4) + h * 32, kk = (tid & 15) * 2;
+        unsigned a1, a2, a3;
+        split3(ra[h * 2 + 0], ra[h * 2 + 1], a1, a2, a3);
+        const int o = row * RS + x3_chunk(row, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<unsigned*>(&Ap[0][o]) = a1;
+        *reinterpret_cast<unsigned*>(&Ap[1][o]) = a2;
+        *reinterpret_cast<unsigned*>(&Ap[2][o]) = a3;
+      }
+    }
+    {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {       // W tile transposed: [column][k], so a fragment's 8 k are contiguous
+        const int idx = tid + h * XT;
+        if (idx >= KT / 2 * NW) continue;
+        const int cc = idx % NW, kk = (idx / NW) * 2;
+        unsigned w1, w2, w3;
+        split3(rw[h * 2 + 0], rw[h * 2 + 1], w1, w2, w3);
+        const int o = cc * RS + x3_chunk(cc, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<unsigned*>(&Wp[0][o]) = w1;
+        *reinterpret_cast<unsigned*>(&Wp[1][o]) = w2;
+        *reinterpret_cast<unsigned*>(&Wp[2][o]) = w3;
+      }
+    }
+  };
+
+  load_tile(0);
+  const int frag = (lane & 15) * RS + x3_chunk(lane & 15, lane >> 4) * 8;   // this lane's 8 consecutive k of row / column (lane & 15)
+  for (int ti = 0; ti < total; ++ti) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (ti + 1 < total) load_tile(ti + 1);
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[r][pl] = *reinterpret_cast<const bf16x8*>(&Ap[pl][(wave * 32 + r * 16) * RS + frag]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 w[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8*>(&Wp[pl][(nt * 16) * RS + frag]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {      // smallest terms first
+        f32x4 c = acc[r][nt];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][2], w[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[0], c, 0, 0, 0);
+        acc[r][nt] = c;
+      }
+    }
+  }
+  // ---- epilogue
+  if constexpr (NT <= 4) {
+    if (p.vec_epilogue) {
+      // accumulators -> wave-private scratch (the A planes are free now) -> float4 rows: coalesced bias loads, 16-byte stores
+      constexpr int ES = NW + 4;                       // scratch row stride in floats
+      constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
+      __syncthreads();                                 // every wave is done reading the last tile's planes
+      float* my = reinterpret_cast<float*>(&Ap[0][0]) + wave * (16 * ES);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * ES + nt * 16 + (lane & 15)] = acc[r][nt][i];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+          const int64_t m = m0 + wave * 32 + r * 16 + row;
+          const int col = n0 + seg;
+          if (m >= p.M || col >= p.N) continue;
+          float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
+          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          if (p.bias_kind && col < p.bias_cols) {
+            const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
+          if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+          *o = v;
+        }
+      }
+      return;
+    }
+  }
+  const int col_l = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wave * 32 + r * 16 + (lane >> 4) * 4 + i;
+      if (m >= p.M) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + col_l;
+        if (col >= p.N) continue;
+        float v = acc[r][nt][i];
+        if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+        else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+        float* o = p.out + orow * p.ldo + col;
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
 // W-resident variant for the common case where the whole folded weight fits in LDS (nterms*Kc*N*4 <= 80 KB).
 // 512 threads = 8 waves; the block loads W once, then every wave streams its own 32-row tiles:
 //   global (float4, row-contiguous) -> registers -> wave-private LDS scratch [32][66] -> MFMA A fragments,
@@ -1350,7 +1567,11 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   const int kc4 = (Kc + 3) / 4 * 4;
   const size_t wbytes = (size_t)nterms * kc4 * nt * 16 * sizeof(float);
   const unsigned gy = (unsigned)((N + nt * 16 - 1) / (nt * 16));
-  if (wbytes <= (size_t)kResMaxWBytes && g_proj_variant.load() != 1) {
+  // project_variant: 0 auto (bf16x3 on large problems, else exact fp32: W-resident when it fits, streaming otherwise),
+  // 1 exact-fp32 streaming, 2 exact-fp32 (W-resident with 16-row wave tiles when it fits), 3 bf16x3 always, 4 exact fp32 auto
+  const int pv = g_proj_variant.load();
+  const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
+  if (wbytes <= (size_t)kResMaxWBytes && pv != 1 && !use_x3) {
     const int rt = g_proj_variant.load() == 2 ? 1 : 2;                  // 8 waves x 32 rows (variant 2: 16 waves x 16 rows)
     const int res_rows = 16 * rt, res_waves = 1024 / rt / 64;
     const size_t lds = wbytes + (size_t)kResScratchFloats * sizeof(float);
@@ -1395,6 +1616,23 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
 #define TGCN_PROJ(NTV)                                                                               \
   if (vec4) hipLaunchKernelGGL((project_kernel<NTV, true>), grid, dim3(kBlock), 0, st, p);             \
   else hipLaunchKernelGGL((project_kernel<NTV, false>), grid, dim3(kBlock), 0, st, p);
+  if (use_x3) {      // bf16x3 products on the bf16 matrix pipe
+    const dim3 grid3((unsigned)((M + 255) / 256), grid.y);
+#define TGCN_PROJ3(NTV)                                                                              \
+  if (vec4) hipLaunchKernelGGL((project_x3_kernel<NTV, true>), grid3, dim3(512), 0, st, p);           \
+  else hipLaunchKernelGGL((project_x3_kernel<NTV, false>), grid3, dim3(512), 0, st, p);
+    switch (nts) {
+      case 1: TGCN_PROJ3(1) break;
+      case 2: TGCN_PROJ3(2) break;
+      case 4: TGCN_PROJ3(4) break;
+      case 6: TGCN_PROJ3(6) break;
+      case 8: TGCN_PROJ3(8) break;
+      default: TGCN_PROJ3(10) break;
+    }
+#undef TGCN_PROJ3
+    TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (bf16x3)");
+    return TGCN_OK;
+  }
   switch (nts) {
     case 1: TGCN_PROJ(1) break;
     case 2: TGCN_PROJ(2) break;

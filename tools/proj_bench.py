@@ -27,10 +27,11 @@ def run(M, Kc, N, T, mode, variant, rounds=5):
     ts = []
     for r in range(rounds + 1):
         _lib.profile_start(16)
-        _lib.check(L.tgcn_cheb_project_f32(_lib.stream_ptr(), M, Kc, N, T, a, lda, _lib.ptr(W), None, 0, M, 1, 0, _lib.ptr(out), N))
+        if True:
+            _lib.check(L.tgcn_cheb_project_f32(_lib.stream_ptr(), M, Kc, N, T, a, lda, _lib.ptr(W), None, 0, M, 1, 0, _lib.ptr(out), N))
         prof = _lib.profile_stop(16)
         if r:
-            ts.append(prof[0][1])
+            ts.append(sum(ms for k, ms in prof if k == 2))
     _lib.check(L.tgcn_set_tuning(b"project_variant", 0))
     t = float(np.median(ts))
     print("M=%d Kc=%d N=%d T=%d %-5s variant %d: %.3f ms  %.1f TFLOP/s  %.2f TB/s" % (
@@ -39,6 +40,6 @@ def run(M, Kc, N, T, mode, variant, rounds=5):
 
 if __name__ == "__main__":
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-    for mode in ("real", "skew", "alias"):
-        for variant in (0, 1):
+    for mode in ("real", "alias"):
+        for variant in (0, 3):
             run(M, 64, 64, 5, mode, variant)
