@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--row-thresh", type=int, default=None)
     ap.add_argument("--seg-len", type=int, default=None)
     ap.add_argument("--seg-key", default="first")
+    ap.add_argument("--only", default="all", choices=["all", "long", "short"], help="keep only the rows above / up to the row threshold (path analysis)")
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
     args = ap.parse_args()
     from tools import synth
@@ -39,6 +40,12 @@ def main():
         args.n, row, col, val = synth.sheet_mesh(300, device=dev)
     else:
         _, row, col, val = synth.rmat(args.n, args.nnz, labeling=args.labeling, device=dev)
+    if args.only != "all":
+        deg = torch.bincount(row, minlength=args.n)
+        thr = args.row_thresh or graph.ROW_THRESH
+        keep = (deg[row] > thr) if args.only == "long" else (deg[row] <= thr)
+        row, col, val = row[keep], col[keep], val[keep]
+        print("kept %d entries (%s rows)" % (row.numel(), args.only), flush=True)
     op = graph.GraphOperand.from_coo(args.n, row, col, val, dev)
     del row, col, val
     s = op.schedule_for(args.C // args.split)
