@@ -38,6 +38,12 @@ def build_workload(name, labeling, device, n_override=None, nnz_override=None):
         _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling=labeling, device=device)
         spec = dict(cls="TGCNCheb", q=16, H=1, f=64, g=64, K=5,
                     desc="R-MAT(0.57,0.19,0.19,0.05) n=%d nnz=%d %s labels, TGCNCheb(L,64,64,K=5), q=T=16" % (n, nnz, labeling))
+    elif name == "cfg5n":
+        # SURVEY.md 8d "narrow variant": same graph, one input channel per time step (F = 16 floats per vertex and hop)
+        n, nnz = n_override or 10_000_000, nnz_override or 160_000_000
+        _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling=labeling, device=device)
+        spec = dict(cls="TGCNCheb", q=16, H=1, f=1, g=64, K=5,
+                    desc="R-MAT(0.57,0.19,0.19,0.05) n=%d nnz=%d %s labels, TGCNCheb(L,1,64,K=5), q=T=16 (narrow)" % (n, nnz, labeling))
     elif name == "cfg4":
         n, row, col, val = synth.sheet_mesh(300, device=device)
         spec = dict(cls="TGCNCheb_H", q=1, H=1200, f=1, g=32, K=5, desc="sheet mesh n=90000 nnz=%d, TGCNCheb_H(L,1,32,5,1200), q=1" % row.numel())

@@ -210,12 +210,14 @@ def test_hop_linearity_large(gpu_device):
 
 @pytest.mark.parametrize("M,Kc,N,T,inter", [(100, 1, 8, 5, 1), (1000, 28, 64, 5, 1), (777, 64, 64, 3, 1), (640, 15, 32, 10, 1),
                                             (333, 7, 5, 2, 1), (1200, 12, 15, 4, 4), (64 * 9, 3, 100, 2, 9), (500, 36, 40, 33, 1),
-                                            (5000, 64, 64, 5, 1), (4100, 200, 32, 3, 1), (70, 130, 17, 2, 1), (20000, 64, 64, 5, 1), (9000, 100, 160, 1, 1)])
-@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+                                            (5000, 64, 64, 5, 1), (4100, 200, 32, 3, 1), (70, 130, 17, 2, 1), (20000, 64, 64, 5, 1), (9000, 100, 160, 1, 1),
+                                            (6000, 1, 64, 5, 16), (4099, 4, 256, 4, 1), (5000, 2, 1024, 8, 1), (4500, 1, 32, 33, 1)])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 def test_project_vs_numpy(M, Kc, N, T, inter, variant, gpu_device):
     """variant 0: shipped choice (bf16x3 on large problems, exact fp32 otherwise); 1: exact-fp32 streaming-W kernel
     everywhere; 3: bf16x3 everywhere (fp32-accurate products on the bf16 matrix pipe); 4: exact fp32, W-resident
-    kernel where the weight fits in LDS."""
+    kernel where the weight fits in LDS; 5: the vector-ALU kernel for narrow contractions (sum of Kc <= 16) wherever it
+    applies (variant 0 picks it from M >= 4096)."""
     from tgcn_amd import functional as F, _lib
     _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", variant))
     rng = np.random.default_rng(M + Kc)

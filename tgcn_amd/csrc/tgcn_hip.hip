@@ -402,6 +402,15 @@ inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3
       default: return false;
     }
   }
+  if (lpr == 4) {
+    switch (v) {
+      case 1: launch_hop<4, 4, 8, 1>(st, p, grid); return true;
+      case 2: launch_hop<4, 4, 4, 2>(st, p, grid); return true;
+      case 3: launch_hop<4, 4, 4, 4>(st, p, grid); return true;
+      case 4: launch_hop<4, 4, 2, 4>(st, p, grid); return true;
+      default: return false;
+    }
+  }
   if (lpr == 64) {
     switch (v) {
       case 1: launch_hop<64, 4, 4, 1>(st, p, grid); return true;
@@ -1023,6 +1032,72 @@ struct WgradParams {
   int32_t Kc, N, nterms, nblocks;
 };
 
+// ---- narrow contraction (sum of Kc over the terms <= 16, e.g. one input channel per time step): the projection is a
+// pure streaming write of (M, N) with a handful of scalars read per row, so it runs on the vector ALU.  W and the
+// block's A values sit in LDS (A staged with coalesced loads, stored so that a thread's 4 rows are one 16-byte read);
+// a thread owns 4 output columns of 4 rows per step; stores are whole 16-byte pieces of an output row.
+// k-ordered fmaf chain per output, like the exact MFMA kernels.
+constexpr int kNarrowMaxK = 16;
+__global__ __launch_bounds__(kBlock) void project_narrow_kernel(const ProjParams p, int iters) {
+  extern __shared__ float sW[];   // (ktot, N) weights, then (ktot, iters, RP, 4) A values
+  const int ktot = p.nterms * p.Kc;
+  const int L = p.N >> 2, RP = kBlock / L;
+  const int rows_per_block = RP * 4 * iters;
+  float* __restrict__ sA = sW + ktot * p.N;
+  const int64_t mb0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t mend = (mb0 + rows_per_block < p.M) ? mb0 + rows_per_block : p.M;
+  const int nrows = (int)(mend - mb0);
+  for (int i = threadIdx.x; i < ktot * p.N; i += kBlock) sW[i] = p.W[i];
+  for (int t = 0; t < p.nterms; ++t) {
+    const float* __restrict__ at = p.a[t] + mb0 * p.lda[t];
+    const int64_t ld = p.lda[t];
+    for (int i = threadIdx.x; i < nrows * p.Kc; i += kBlock) {
+      const int l = i / p.Kc, kc = i - l * p.Kc;                 // local row = (it * 4 + j) * RP + r
+      const int it = l / (4 * RP), rem = l - it * 4 * RP, j = rem / RP, r = rem - j * RP;
+      sA[(((t * p.Kc + kc) * iters + it) * RP + r) * 4 + j] = at[(int64_t)l * ld + kc];
+    }
+  }
+  __syncthreads();
+  const int r_in = threadIdx.x / L, c4 = (threadIdx.x % L) * 4;
+  if (r_in >= RP) return;
+  for (int it = 0; it * 4 * RP < nrows; ++it) {
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+    for (int kk = 0; kk < ktot; ++kk) {
+      const float4 w = *reinterpret_cast<const float4*>(sW + kk * p.N + c4);
+      const float4 a4 = *reinterpret_cast<const float4*>(sA + ((kk * iters + it) * RP + r_in) * 4);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j][0] = fmaf(av[j], w.x, acc[j][0]);
+        acc[j][1] = fmaf(av[j], w.y, acc[j][1]);
+        acc[j][2] = fmaf(av[j], w.z, acc[j][2]);
+        acc[j][3] = fmaf(av[j], w.w, acc[j][3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = mb0 + (it * 4 + j) * RP + r_in;
+      if (m >= mend) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      if (p.bias_kind && c4 < p.bias_cols) {
+        const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + c4);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + c4);
+      if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+      using f4 = __attribute__((ext_vector_type(4))) float;
+      __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(o));   // written once, read by a later kernel
+    }
+  }
+}
+
+
 constexpr int kWgTerms = 5;   // terms accumulated at once per wave (register budget: 5 * 4 tiles * 4 regs)
 
 __global__ __launch_bounds__(kBlock) void wgrad_partial_kernel(const WgradParams p) {
@@ -1568,8 +1643,27 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   const size_t wbytes = (size_t)nterms * kc4 * nt * 16 * sizeof(float);
   const unsigned gy = (unsigned)((N + nt * 16 - 1) / (nt * 16));
   // project_variant: 0 auto (bf16x3 on large problems, else exact fp32: W-resident when it fits, streaming otherwise),
-  // 1 exact-fp32 streaming, 2 exact-fp32 (W-resident with 16-row wave tiles when it fits), 3 bf16x3 always, 4 exact fp32 auto
+  // 1 exact-fp32 streaming, 2 exact-fp32 (W-resident with 16-row wave tiles when it fits), 3 bf16x3 always, 4 exact fp32 auto,
+  // 5 vector-ALU kernel whenever it applies (auto uses it for sum(Kc) <= 16 and M >= 4096)
   const int pv = g_proj_variant.load();
+  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && win_n == 0 && p.vec_epilogue && N <= 1024 &&
+      (M >= 4096 || pv == 5)) {
+    // a few scalars per row: stream the output from the vector ALU (project_narrow_kernel)
+    const int L = N / 4, RP = kBlock / L;
+    const int ktot = Kc * nterms;
+    int iters = (40 * 1024 / 4 - ktot * N) / (ktot * RP * 4);    // A values of a block: about 40 KB of LDS with the weights
+    iters = iters < 1 ? 1 : (iters > 16 ? 16 : iters);
+    const int rows_per_block = RP * 4 * iters;
+    const int64_t nb = (M + rows_per_block - 1) / rows_per_block;
+    if (nb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
+    const size_t lds = ((size_t)ktot * N + (size_t)ktot * rows_per_block) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)project_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    ProfScope ps(TGCN_PROF_PROJECT, st);
+    hipLaunchKernelGGL(project_narrow_kernel, dim3((unsigned)nb), dim3(kBlock), lds, st, p, iters);
+    TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (narrow)");
+    return TGCN_OK;
+  }
   const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
   if (wbytes <= (size_t)kResMaxWBytes && pv != 1 && !use_x3) {
     const int rt = g_proj_variant.load() == 2 ? 1 : 2;                  // 8 waves x 32 rows (variant 2: 16 waves x 16 rows)
