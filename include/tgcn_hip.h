@@ -90,6 +90,8 @@ int tgcn_abi_version(void);
 #define TGCN_PROF_PROJECT 2
 #define TGCN_PROF_RELAYOUT 3
 #define TGCN_PROF_SMALL 4
+#define TGCN_PROF_WGRAD 5
+#define TGCN_PROF_SMALL_BASIS 6
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 
@@ -172,7 +174,7 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
                              int64_t n, int32_t C, int32_t N, const float* x, const float* Wcat, const float* bias,
                              int32_t bias_kind, float* out, void* workspace, size_t workspace_bytes);
 
-/* Small graphs (n <= 1024, C <= 32, CSR + activations fit in 160 KB of LDS -- the reference's own MNIST / coarsened
+/* Small graphs (n <= 1024, C <= 128, CSR + activations fit in 160 KB of LDS -- the reference's own MNIST / coarsened
  * graphs): the whole layer in ONE launch, recursion run on the output side in LDS (Horner for mode 0, Clenshaw for
  * mode 1).  W: (K, C, N) contiguous; `fold` (nullable, device, K x K): the reference_power -> monomial fold matrix,
  * applied while the weight is staged so the caller passes the layer's raw weight.
@@ -181,6 +183,16 @@ int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t
 int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
                                 const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
                                 float* out);
+
+/* Backward of the same shapes.  The input gradient is the forward kernel itself on the transposed operand
+ * (dx = sum_j (L^T)^j g W_j^T: call tgcn_cheb_forward_small_f32 with A = L^T, x = g, W = the (K, N, C) transposed
+ * working-basis weight, no bias).  The weight gradient needs the basis: tgcn_cheb_basis_small_f32 writes terms
+ * k = 1 .. K-1 of the (K, q, n, C) stack in ONE launch (mode 0: monomials L^k x, the basis of the folded weight;
+ * mode 1: Chebyshev T_k x); term 0 is x itself and is not copied.  Feed the terms to tgcn_cheb_wgrad_f32.
+ * _supported returns the channel tile (16 / 8 / 4) or 0 when the operand does not fit in LDS. */
+int tgcn_cheb_basis_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode);
+int tgcn_cheb_basis_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C,
+                              const float* x, float* stack);
 
 /* Fused epilogue of the callers' pattern  x = gcn_pool_4(F.relu(layer(x)))  (examples/pytorch_based/
  * pytorch_hcp_tgcn.py:134-141): out (q, n/pool, N) = max over `pool` consecutive vertices of

@@ -314,8 +314,36 @@ def test_forward_layouts_agree(layout, q_chunk, gpu_device):
         assert rel_err(out.cpu().numpy(), ref) <= TOL
 
 
+@pytest.mark.parametrize("n,q,C,K", [(784, 3, 28, 5), (300, 5, 1, 6), (148, 9, 15, 10), (1000, 2, 32, 3), (64, 7, 13, 4), (500, 2, 40, 2), (90, 3, 6, 1)])
+def test_small_basis_kernel_vs_oracle(n, q, C, K, gpu_device):
+    """One-launch basis kernel (terms of the weight gradient on small graphs): monomials L^k x for mode 0, Chebyshev
+    T_k x for mode 1; sparse and dense LDS forms of the operand."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(n + K)
+    deg = 100 if n == 148 else 6                      # n = 148: dense like the DTI graph -> dense LDS form
+    row, col, val = _random_graph(n, deg, rng, hubs=((3, 40),), isolated=(0, 9))
+    val = val * (0.05 if n == 148 else 0.5)
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((q, n, C)).astype(np.float32)
+    for mode in (F.MODE_POWER, F.MODE_CHEBYSHEV):
+        assert F.small_basis_tile(op, C, mode) in (4, 8, 16)
+        if mode == F.MODE_POWER:
+            P = [x.astype(np.float64)]
+            for _ in range(1, K):
+                P.append(O._apply(L.astype(np.float64), P[-1]))
+            ref = np.stack(P)
+        else:
+            ref = O.stack_chebyshev(L.astype(np.float64), x.astype(np.float64), K)
+        terms = F.cheb_basis_small(op, _dev(x), K, mode)
+        assert len(terms) == K
+        for k in range(K):
+            assert rel_err(terms[k].cpu().numpy(), ref[k]) <= TOL, (mode, k)
+
+
 @pytest.mark.parametrize("n,q,Crow,N,K", [(784, 5, 28, 64, 5), (300, 3, 1, 8, 5), (1000, 2, 32, 15, 3), (64, 7, 12, 70, 10), (500, 2, 5, 16, 1),
-                                          (200, 3, 17, 33, 25)])
+                                          (200, 3, 17, 33, 25), (784, 2, 64, 28, 5), (300, 3, 40, 7, 4), (148, 4, 100, 12, 3), (100, 2, 33, 16, 6)])
 def test_small_graph_kernel_vs_oracle(n, q, Crow, N, K, gpu_device):
     """The one-launch LDS-resident path (Horner / Clenshaw on the output side) against the oracle, both modes,
     all bias kinds, in-kernel weight fold."""
@@ -360,12 +388,18 @@ def test_streaming_windows_match_windowed_batch(n, S, T, H, g, K, gpu_device):
 
 
 # ------------------------------------------------------------------------------------------ backward
+@pytest.mark.parametrize("shape", [(60, 3, 5, 4, 2, 6), (300, 2, 4, 7, 4, 64), (90, 5, 3, 1, 1, 40)])
+@pytest.mark.parametrize("small", [True, False])
 @pytest.mark.parametrize("cls", ["GCNCheb", "TGCNCheb_H", "ChebConv", "ChebTimeConv"])
-def test_backward_vs_dense_autograd(cls, gpu_device):
-    """Gradients of the HIP layer against torch autograd through a dense fp64 restatement of the same formula."""
+def test_backward_vs_dense_autograd(cls, small, shape, gpu_device, monkeypatch):
+    """Gradients of the HIP layer against torch autograd through a dense fp64 restatement of the same formula.
+    small=True: graphs that fit in LDS take the one-launch kernels (forward, basis for dW, forward on L^T for dx);
+    small=False: the same shapes through the general hop / projection / weight-gradient kernels."""
     import tgcn_amd
+    from tgcn_amd import functional as F
+    monkeypatch.setattr(F, "SMALL_PATH", small)
     rng = np.random.default_rng(11)
-    n, q, K, H, f, g = 60, 3, 5, 4, 2, 6
+    n, q, K, H, f, g = shape
     row, col, val = _random_graph(n, 5, rng)
     A = O.coo_to_csr(row, col, np.abs(val), n)
     A = ((A + A.T) > 0).astype(np.float32)

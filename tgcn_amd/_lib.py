@@ -66,6 +66,9 @@ SIGNATURES = {
                                         C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P,
                                         C.c_int32, C.c_int64, _P, C.c_size_t]),
     "tgcn_cheb_forward_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_cheb_basis_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_cheb_basis_small_f32": (C.c_int, [C.c_void_p, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                           C.c_void_p, C.c_void_p]),
     "tgcn_cheb_forward_small_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                               _P, _P, _P, _P, C.c_int32, _P]),
     "tgcn_cheb_forward_small_pool_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
@@ -121,7 +124,12 @@ def require_device(*tensors):
 
 
 def stream_ptr():
+    """Raw handle of torch's current stream on the current device (the private accessor skips building a Stream
+    object: 1 us instead of 25 us per call on the latency-bound small-graph path)."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -14,6 +14,8 @@
 
 #include <atomic>
 #include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "tgcn_hip.h"
@@ -358,6 +360,17 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
   g.nchunks = (lanes + lpr - 1) / lpr;
   g.cpad = g.nchunks * lpr * g.vec;
   return g;
+}
+
+// Kernels that take more than 64 KB of dynamic LDS.  The attribute belongs to the calling thread's current device
+// (nn.DataParallel drives several devices from one process), so it is set once per (device, kernel).
+inline void allow_large_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert(std::make_pair(dev, fn)).second) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 std::atomic<int> g_hop_variant{0};
@@ -1100,61 +1113,91 @@ __global__ __launch_bounds__(kBlock) void project_narrow_kernel(const ProjParams
 
 constexpr int kWgTerms = 5;   // terms accumulated at once per wave (register budget: 5 * 4 tiles * 4 regs)
 
-__global__ __launch_bounds__(kBlock) void wgrad_partial_kernel(const WgradParams p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wave per (row block, 64-column tile of G, 16-row tile of the weight): dW_t tile = A_t^T G over the block's rows
+// on the fp32 MFMA (k = 4 rows per instruction), fragments straight from global memory, kWgUnroll steps of loads in
+// flight.  Row blocks are small (>= 64 rows) so that a few thousand waves cover even the q*n ~ 50 k rows of the
+// small-graph configs; the per-block partials are folded in block order by wgrad_reduce_kernel (deterministic).
+constexpr int kWgUnroll = 4;
+__global__ __launch_bounds__(64) void wgrad_partial_kernel(const WgradParams p) {
+  const int lane = threadIdx.x;
   const int r = lane & 15, kq = lane >> 4;
   const int64_t m_lo = (int64_t)blockIdx.x * p.rows_per_block;
   const int64_t m_hi = min(p.M, m_lo + p.rows_per_block);
   const int n0 = blockIdx.y * 64;
-  const int ctiles = (p.Kc + 15) / 16;
+  const int ct = blockIdx.z;
   float* part = p.partial + (size_t)blockIdx.x * p.nterms * p.Kc * p.N;
-  for (int ct = wave; ct < ctiles; ct += 4) {
-    const int c = ct * 16 + r;
-    for (int t0 = 0; t0 < p.nterms; t0 += kWgTerms) {
-      f32x4 acc[kWgTerms][4];
+  const int c = ct * 16 + r;
+  for (int t0 = 0; t0 < p.nterms; t0 += kWgTerms) {
+    f32x4 acc[kWgTerms][4];
 #pragma unroll
-      for (int t = 0; t < kWgTerms; ++t)
+    for (int t = 0; t < kWgTerms; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int64_t m0 = m_lo; m0 < m_hi; m0 += 4) {
-        const int64_t m = m0 + kq;
+      for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t m0 = m_lo; m0 < m_hi; m0 += 4 * kWgUnroll) {
+      float gv[kWgUnroll][4], av[kWgUnroll][kWgTerms];
+#pragma unroll
+      for (int u = 0; u < kWgUnroll; ++u) {
+        const int64_t m = m0 + u * 4 + kq;
         const bool mok = m < m_hi;
-        float gv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = n0 + j * 16 + r;
-          gv[j] = (mok && n < p.N) ? p.G[m * p.ldg + n] : 0.f;
+          gv[u][j] = (mok && n < p.N) ? p.G[m * p.ldg + n] : 0.f;
         }
+#pragma unroll
+        for (int t = 0; t < kWgTerms; ++t)
+          av[u][t] = (mok && c < p.Kc && t0 + t < p.nterms) ? p.a[t0 + t][m * p.lda[t0 + t] + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kWgUnroll; ++u)
 #pragma unroll
         for (int t = 0; t < kWgTerms; ++t) {
           if (t0 + t >= p.nterms) break;
-          const float av = (mok && c < p.Kc) ? p.a[t0 + t][m * p.lda[t0 + t] + c] : 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gv[j], acc[t][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t], gv[u][j], acc[t][j], 0, 0, 0);
         }
-      }
-      // D layout: col = lane&15 (n within tile), row = (lane>>4)*4 + i (c within tile)
+    }
+    // D layout: col = lane&15 (n within tile), row = (lane>>4)*4 + i (c within tile)
 #pragma unroll
-      for (int t = 0; t < kWgTerms; ++t) {
-        if (t0 + t >= p.nterms) break;
+    for (int t = 0; t < kWgTerms; ++t) {
+      if (t0 + t >= p.nterms) break;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int cc = ct * 16 + kq * 4 + i, n = n0 + j * 16 + r;
-            if (cc < p.Kc && n < p.N) part[((size_t)(t0 + t) * p.Kc + cc) * p.N + n] = acc[t][j][i];
-          }
-      }
+        for (int i = 0; i < 4; ++i) {
+          const int cc = ct * 16 + kq * 4 + i, n = n0 + j * 16 + r;
+          if (cc < p.Kc && n < p.N) part[((size_t)(t0 + t) * p.Kc + cc) * p.N + n] = acc[t][j][i];
+        }
     }
   }
 }
 
-__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const WgradParams p) {
+// Folds the per-block partials: workgroup = 64 consecutive elements of dW x 16 waves, wave w sums its contiguous
+// share of the blocks (four interleaved chains, 256-byte coalesced reads), the 16 shares are combined through LDS in
+// wave order -> the same association for every launch.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams p) {
+  __shared__ float red[16][64];
   const int64_t total = (int64_t)p.nterms * p.Kc * p.N;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
-    float s = 0.f;
-    for (int b = 0; b < p.nblocks; ++b) s += p.partial[(size_t)b * total + e];
-    p.dW[e] = s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  const int per = (p.nblocks + 15) / 16;
+  const int b0 = wave * per, b1 = min(p.nblocks, b0 + per);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e < total) {
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += p.partial[(size_t)(b + u) * total + e];
+    }
+    for (; b < b1; ++b) s[0] += p.partial[(size_t)b * total + e];
+  }
+  red[wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (wave == 0 && e < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    p.dW[e] = t;
   }
 }
 
@@ -1165,10 +1208,12 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const WgradParams 
 // LDS instead of n x C x K hop tensors in HBM):
 //   mode 0 (monomial-folded weight, Horner):  Y_j = X W_j + L Y_{j+1},                     out = Y_0 + bias
 //   mode 1 (Chebyshev weight, Clenshaw):      b_k = X W_k + 2 L b_{k+1} - b_{k+2},         out = X W_0 + L b_1 - b_2 + bias
-// Thread t owns vertex t (up to 1024 threads) and keeps its input row in registers; X W_j is VALU fmaf,
+// Thread t owns vertex t (up to 1024 threads) and keeps its input row in registers (rows longer than 32 floats are
+// re-read from global memory in 32-float pieces every step: 8 loads against 512 fmaf); X W_j is VALU fmaf,
 // L . is a walk over the LDS-resident CSR reading neighbour rows of the previous buffer from LDS.
 constexpr int kSmallMaxN = 1024;  // one thread per vertex
-constexpr int kSmallCMax = 32;    // input row length held in registers
+constexpr int kSmallCMax = 128;   // longest input row; up to 32 floats of it live in registers at a time
+inline int small_cpad(int C) { return C <= 4 ? 4 : (C <= 16 ? 16 : (C + 31) / 32 * 32); }   // rows of the LDS weight tile
 
 struct SmallParams {
   const int32_t* rowptr;
@@ -1183,7 +1228,7 @@ struct SmallParams {
   uint8_t* pool_idx;       // (q, n/pool, N) arg-max offset for the backward (nullable)
 };
 
-template <int NTC, int CP>   // CP: input row length padded (registers), C <= CP
+template <int NTC, int CP>   // CP: floats of the input row held in registers (C <= CP, or CP == 32 and C in pieces)
 __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallParams p) {
   extern __shared__ __align__(16) float smem[];
   const int n = p.n, nnz = p.nnz, C = p.C;
@@ -1202,7 +1247,9 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
   const int slot = tid / p.npad, li = tid % p.npad;
   const int q = blockIdx.x * p.spw + slot, n0 = blockIdx.y * NTC;
   const bool live = q < p.q;
-  float* Ybase = Wt + CP * NTC + slot * (nbuf * n * NTC);            // this sample's NB buffers of n x NTC
+  const int cpad = (C + CP - 1) / CP * CP;                          // rows of the weight tile
+  const bool pieces = C > CP;                                       // input row longer than the register copy
+  float* Ybase = Wt + cpad * NTC + slot * (nbuf * n * NTC);         // this sample's NB buffers of n x NTC
 
   // ---- stage CSR and this sample's input (through the Y buffers, which are free now) into LDS / registers
   if (p.dense) {
@@ -1217,8 +1264,8 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
   float xr[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) xr[c] = 0.f;
-  {
-    const float* xq = p.x + (int64_t)(live ? q : 0) * n * C;
+  const float* xq = p.x + (int64_t)(live ? q : 0) * n * C;
+  if (!pieces) {
     const int total = n * C, cap = nbuf * n * NTC;
     for (int base = 0; base < total; base += cap) {     // one piece unless C > nbuf*NTC
       const int cnt = min(cap, total - base);
@@ -1238,7 +1285,7 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
   int cur = 0;   // buffer that receives this step's result
   for (int j = p.K - 1; j >= 0; --j) {
     // ---- weight tile of this step -> LDS (folding the reference_power basis on the fly when asked to)
-    for (int e = tid; e < CP * NTC; e += nthr) {       // rows c >= C and columns >= N are zero
+    for (int e = tid; e < cpad * NTC; e += nthr) {     // rows c >= C and columns >= N are zero
       const int c = e / NTC, g = e % NTC;
       float w = 0.f;
       if (c < C && n0 + g < p.N) {
@@ -1303,19 +1350,35 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
           }
         }
       }
+      for (int cb = 0; cb < cpad; cb += CP) {          // + X W_j  (padded rows of Wt are zero: no per-c condition)
+        if (pieces) {                                   // this piece of the own input row, straight from global / L2
+          const float* xrow = xq + (int64_t)i * C + cb;
+          if ((C & 3) == 0) {
 #pragma unroll
-      for (int c = 0; c < CP; ++c) {                  // + X W_j  (padded rows of Wt are zero: no per-c condition)
-        const float xv = xr[c];
-        const float4* wrow = reinterpret_cast<const float4*>(Wt + c * NTC);
+            for (int c4 = 0; c4 < CP / 4; ++c4) {
+              float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (cb + c4 * 4 < C) v = reinterpret_cast<const float4*>(xrow)[c4];
+              xr[c4 * 4] = v.x; xr[c4 * 4 + 1] = v.y; xr[c4 * 4 + 2] = v.z; xr[c4 * 4 + 3] = v.w;
+            }
+          } else {
 #pragma unroll
-        for (int g4 = 0; g4 < NTC / 4; ++g4) {
-          const float4 w = wrow[g4];
-          acc[g4 * 4 + 0] = fmaf(xv, w.x, acc[g4 * 4 + 0]);
-          acc[g4 * 4 + 1] = fmaf(xv, w.y, acc[g4 * 4 + 1]);
-          acc[g4 * 4 + 2] = fmaf(xv, w.z, acc[g4 * 4 + 2]);
-          acc[g4 * 4 + 3] = fmaf(xv, w.w, acc[g4 * 4 + 3]);
+            for (int c = 0; c < CP; ++c) xr[c] = cb + c < C ? xrow[c] : 0.f;
+          }
         }
-        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled LDS reads from piling up in registers
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+          const float xv = xr[c];
+          const float4* wrow = reinterpret_cast<const float4*>(Wt + (cb + c) * NTC);
+#pragma unroll
+          for (int g4 = 0; g4 < NTC / 4; ++g4) {
+            const float4 w = wrow[g4];
+            acc[g4 * 4 + 0] = fmaf(xv, w.x, acc[g4 * 4 + 0]);
+            acc[g4 * 4 + 1] = fmaf(xv, w.y, acc[g4 * 4 + 1]);
+            acc[g4 * 4 + 2] = fmaf(xv, w.z, acc[g4 * 4 + 2]);
+            acc[g4 * 4 + 3] = fmaf(xv, w.w, acc[g4 * 4 + 3]);
+          }
+          if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled LDS reads from piling up in registers
+        }
       }
       if (j > 0) {
         const int swi = (i >> 2) & (NTC / 4 - 1);
@@ -1368,10 +1431,10 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
   }
 }
 
-inline size_t small_lds_bytes(int n, int nnz, int ntc, int mode, int dense, int spw = 1) {
+inline size_t small_lds_bytes(int n, int nnz, int C, int ntc, int mode, int dense, int spw = 1) {
   const size_t graph = dense ? (size_t)((n * (n | 1) + 3) / 4 * 4)
                              : 2 * (size_t)((nnz + 1) / 2 * 2) + (size_t)((n + 1 + 3) / 4 * 4);
-  const size_t fl = graph + (size_t)kSmallCMax * ntc + (size_t)spw * (mode == 0 ? 2 : 3) * n * ntc;
+  const size_t fl = graph + (size_t)small_cpad(C) * ntc + (size_t)spw * (mode == 0 ? 2 : 3) * n * ntc;
   return fl * sizeof(float);
 }
 
@@ -1380,12 +1443,145 @@ inline int small_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int* de
   if (n < 1 || n > (int64_t)kSmallMaxN || nnz < 0 || nnz > (1 << 20) || C < 1 || C > kSmallCMax) return 0;
   if (mode != 0 && mode != 1) return 0;
   for (int ntc = 16; ntc >= 8; ntc /= 2) {
-    const size_t sparse_b = small_lds_bytes((int)n, (int)nnz, ntc, mode, 0);
-    const size_t dense_b = n <= 512 ? small_lds_bytes((int)n, (int)nnz, ntc, mode, 1) : (size_t)-1;
+    const size_t sparse_b = small_lds_bytes((int)n, (int)nnz, C, ntc, mode, 0);
+    const size_t dense_b = n <= 512 ? small_lds_bytes((int)n, (int)nnz, C, ntc, mode, 1) : (size_t)-1;
     const size_t best = sparse_b < dense_b ? sparse_b : dense_b;
     if (best <= 160 * 1024) {
       *dense = dense_b < sparse_b;
       return ntc;
+    }
+  }
+  return 0;
+}
+
+// ---- the basis of the layer for small graphs, for the weight gradient: terms k = 1 .. K-1 of
+//   mode 0:  P_k = L P_{k-1}                      (monomials, the basis of the folded weight)
+//   mode 1:  T_k = 2 L T_{k-1} - T_{k-2}          (T_1 = L x)
+// written to stack (K, q, n, C) (term 0 is x itself and is not copied).  Same LDS-resident operand and thread = vertex
+// layout as small_forward_kernel; workgroup = (spw samples, tile of CT input channels).
+template <int CT>
+__global__ __launch_bounds__(kSmallMaxN) void small_basis_kernel(const SmallParams p) {
+  extern __shared__ __align__(16) float smem[];
+  const int n = p.n, nnz = p.nnz, C = p.C;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  const int ldn = n | 1;
+  tgcn_edge* ev = reinterpret_cast<tgcn_edge*>(smem);
+  int32_t* rowptr = reinterpret_cast<int32_t*>(smem + 2 * ((nnz + 1) / 2 * 2));
+  float* Ld = smem;
+  float* Y0 = p.dense ? smem + (n * ldn + 3) / 4 * 4 : reinterpret_cast<float*>(rowptr) + (n + 1 + 3) / 4 * 4;
+  const int nbuf = p.mode == 0 ? 2 : 3;
+  const int slot = tid / p.npad, i = tid % p.npad;
+  const int q = blockIdx.x * p.spw + slot, c0 = blockIdx.y * CT;
+  const bool live = q < p.q && i < n;
+  float* Ybase = Y0 + slot * (nbuf * n * CT);
+  if (p.dense) {
+    for (int e = tid; e < n * ldn; e += nthr) Ld[e] = 0.f;
+    __syncthreads();
+    if (tid < n)
+      for (int e = p.rowptr[tid]; e < p.rowptr[tid + 1]; ++e) Ld[tid * ldn + p.ev[e].col] += p.ev[e].val;
+  } else {
+    for (int e = tid; e < nnz; e += nthr) ev[e] = p.ev[e];
+    for (int r = tid; r <= n; r += nthr) rowptr[r] = p.rowptr[r];
+  }
+  const int swi = (i >> 2) & (CT / 4 - 1);       // rows are stored with their 16-byte quads XOR-swizzled
+  if (live) {
+    const float* xr = p.x + ((int64_t)q * n + i) * C + c0;
+#pragma unroll
+    for (int g4 = 0; g4 < CT / 4; ++g4) {
+      float4 v;
+      v.x = c0 + g4 * 4 + 0 < C ? xr[g4 * 4 + 0] : 0.f;
+      v.y = c0 + g4 * 4 + 1 < C ? xr[g4 * 4 + 1] : 0.f;
+      v.z = c0 + g4 * 4 + 2 < C ? xr[g4 * 4 + 2] : 0.f;
+      v.w = c0 + g4 * 4 + 3 < C ? xr[g4 * 4 + 3] : 0.f;
+      reinterpret_cast<float4*>(Ybase + i * CT)[g4 ^ swi] = v;
+    }
+  }
+  __syncthreads();
+  int cur = 1;   // buffer that receives this step's result; buffer 0 holds x
+  for (int k = 1; k < p.K; ++k) {
+    const float* B1 = Ybase + ((cur + nbuf - 1) % nbuf) * n * CT;
+    const float* B2 = Ybase + ((cur + nbuf - 2) % nbuf) * n * CT;
+    float* Yn = Ybase + cur * n * CT;
+    if (live) {
+      float acc[CT];
+#pragma unroll
+      for (int g = 0; g < CT; ++g) acc[g] = 0.f;
+      if (p.dense) {
+        for (int col = 0; col < n; ++col) {
+          const float lv = Ld[i * ldn + col];
+          const float4* src = reinterpret_cast<const float4*>(B1 + col * CT);
+          const int sw = (col >> 2) & (CT / 4 - 1);
+#pragma unroll
+          for (int g4 = 0; g4 < CT / 4; ++g4) {
+            const float4 y = src[g4 ^ sw];
+            acc[g4 * 4 + 0] = fmaf(lv, y.x, acc[g4 * 4 + 0]);
+            acc[g4 * 4 + 1] = fmaf(lv, y.y, acc[g4 * 4 + 1]);
+            acc[g4 * 4 + 2] = fmaf(lv, y.z, acc[g4 * 4 + 2]);
+            acc[g4 * 4 + 3] = fmaf(lv, y.w, acc[g4 * 4 + 3]);
+          }
+        }
+      } else {
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+          const tgcn_edge ed = ev[e];
+          const float4* src = reinterpret_cast<const float4*>(B1 + ed.col * CT);
+          const int sw = (ed.col >> 2) & (CT / 4 - 1);
+#pragma unroll
+          for (int g4 = 0; g4 < CT / 4; ++g4) {
+            const float4 y = src[g4 ^ sw];
+            acc[g4 * 4 + 0] = fmaf(ed.val, y.x, acc[g4 * 4 + 0]);
+            acc[g4 * 4 + 1] = fmaf(ed.val, y.y, acc[g4 * 4 + 1]);
+            acc[g4 * 4 + 2] = fmaf(ed.val, y.z, acc[g4 * 4 + 2]);
+            acc[g4 * 4 + 3] = fmaf(ed.val, y.w, acc[g4 * 4 + 3]);
+          }
+        }
+      }
+      if (p.mode == 1 && k >= 2) {                // one rounding, like 2*X - Xt[k-2] of the reference
+#pragma unroll
+        for (int g4 = 0; g4 < CT / 4; ++g4) {
+          const float4 z = reinterpret_cast<const float4*>(B2 + i * CT)[g4 ^ swi];
+          acc[g4 * 4 + 0] = fmaf(2.f, acc[g4 * 4 + 0], -z.x);
+          acc[g4 * 4 + 1] = fmaf(2.f, acc[g4 * 4 + 1], -z.y);
+          acc[g4 * 4 + 2] = fmaf(2.f, acc[g4 * 4 + 2], -z.z);
+          acc[g4 * 4 + 3] = fmaf(2.f, acc[g4 * 4 + 3], -z.w);
+        }
+      }
+      float* o = p.out + (((int64_t)k * p.q + q) * n + i) * C + c0;
+      if (c0 + CT <= C && (C & 3) == 0) {
+#pragma unroll
+        for (int g4 = 0; g4 < CT / 4; ++g4)
+          reinterpret_cast<float4*>(o)[g4] = make_float4(acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < CT; ++g)
+          if (c0 + g < C) o[g] = acc[g];
+      }
+      if (k + 1 < p.K) {
+#pragma unroll
+        for (int g4 = 0; g4 < CT / 4; ++g4)
+          reinterpret_cast<float4*>(Yn + i * CT)[g4 ^ swi] = make_float4(acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+      }
+    }
+    __syncthreads();
+    cur = (cur + 1) % nbuf;
+  }
+}
+
+inline size_t basis_lds_bytes(int n, int nnz, int ct, int mode, int dense, int spw = 1) {
+  const size_t graph = dense ? (size_t)((n * (n | 1) + 3) / 4 * 4)
+                             : 2 * (size_t)((nnz + 1) / 2 * 2) + (size_t)((n + 1 + 3) / 4 * 4);
+  return (graph + (size_t)spw * (mode == 0 ? 2 : 3) * n * ct) * sizeof(float);
+}
+
+// -> channel tile (16 / 8 / 4) of small_basis_kernel, 0 when the operand does not fit
+inline int basis_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int* dense) {
+  if (n < 1 || n > (int64_t)kSmallMaxN || nnz < 0 || nnz > (1 << 20) || C < 1 || (mode != 0 && mode != 1)) return 0;
+  for (int ct = (C <= 4 ? 4 : (C <= 8 ? 8 : 16)); ct >= 4; ct /= 2) {
+    const size_t sparse_b = basis_lds_bytes((int)n, (int)nnz, ct, mode, 0);
+    const size_t dense_b = n <= 512 ? basis_lds_bytes((int)n, (int)nnz, ct, mode, 1) : (size_t)-1;
+    const size_t best = sparse_b < dense_b ? sparse_b : dense_b;
+    if (best <= 160 * 1024) {
+      *dense = dense_b < sparse_b;
+      return ct;
     }
   }
   return 0;
@@ -1657,8 +1853,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     const int64_t nb = (M + rows_per_block - 1) / rows_per_block;
     if (nb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
     const size_t lds = ((size_t)ktot * N + (size_t)ktot * rows_per_block) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)project_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    allow_large_lds((const void*)project_narrow_kernel, 160 * 1024);
     ProfScope ps(TGCN_PROF_PROJECT, st);
     hipLaunchKernelGGL(project_narrow_kernel, dim3((unsigned)nb), dim3(kBlock), lds, st, p, iters);
     TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (narrow)");
@@ -1676,14 +1871,8 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     ProfScope ps(TGCN_PROF_PROJECT, st);
 #define TGCN_PROJ_R(NTV, V4)                                                                                  \
   {                                                                                                           \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      hipFuncSetAttribute((const void*)project_resident_kernel<NTV, V4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          kResMaxWBytes + kResScratchFloats * (int)sizeof(float));                            \
-      hipFuncSetAttribute((const void*)project_resident_kernel<NTV, V4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          kResMaxWBytes + kResScratchFloats * (int)sizeof(float));                            \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
+    allow_large_lds((const void*)project_resident_kernel<NTV, V4, 1>, kResMaxWBytes + kResScratchFloats * (int)sizeof(float)); \
+    allow_large_lds((const void*)project_resident_kernel<NTV, V4, 2>, kResMaxWBytes + kResScratchFloats * (int)sizeof(float)); \
     if (rt == 1) hipLaunchKernelGGL((project_resident_kernel<NTV, V4, 1>), grid, dim3(1024), lds, st, p, kc4, ntiles); \
     else hipLaunchKernelGGL((project_resident_kernel<NTV, V4, 2>), grid, dim3(512), lds, st, p, kc4, ntiles);          \
   }
@@ -1740,10 +1929,14 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   return TGCN_OK;
 }
 
+static int64_t wgrad_rows_per_block(int64_t M) {
+  int64_t rpb = (M + 1023) / 1024;            // at most 1024 row blocks (partials to fold) ...
+  if (rpb < 64) rpb = 64;                     // ... of at least 64 rows
+  return (rpb + 15) / 16 * 16;
+}
 static int wgrad_blocks(int64_t M) {
-  int64_t b = (M + 1023) / 1024;   // >= 1024 rows per block
-  if (b > 1024) b = 1024;
-  return (int)(b < 1 ? 1 : b);
+  const int64_t rpb = wgrad_rows_per_block(M);
+  return (int)((M + rpb - 1) / rpb);
 }
 
 size_t tgcn_cheb_wgrad_workspace_bytes(int64_t M, int32_t Kc, int32_t N, int32_t nterms) {
@@ -1766,11 +1959,14 @@ int tgcn_cheb_wgrad_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   }
   p.G = G; p.partial = (float*)workspace; p.dW = dW; p.M = M; p.ldg = ldg;
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.nblocks = wgrad_blocks(M);
-  p.rows_per_block = ((M + p.nblocks - 1) / p.nblocks + 3) / 4 * 4;
-  p.nblocks = (int)((M + p.rows_per_block - 1) / p.rows_per_block);
+  p.rows_per_block = wgrad_rows_per_block(M);
+  const int ctiles = (Kc + 15) / 16;
+  if ((N + 63) / 64 > 65535 || ctiles > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "wgrad: Kc=%d N=%d too wide", Kc, N);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(p.nblocks, (N + 63) / 64), dim3(kBlock), 0, st, p);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_1d((int64_t)nterms * Kc * N)), dim3(kBlock), 0, st, p);
+  { ProfScope ps(TGCN_PROF_WGRAD, st);
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(p.nblocks, (N + 63) / 64, ctiles), dim3(64), 0, st, p); }
+  { ProfScope ps(TGCN_PROF_WGRAD, st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)nterms * Kc * N + 63) / 64)), dim3(1024), 0, st, p); }
   TGCN_CHECK_LAUNCH("tgcn_cheb_wgrad_f32");
   return TGCN_OK;
 }
@@ -1843,25 +2039,64 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
   p.npad = (p.n + 63) / 64 * 64;
   int spw = 1;
   const int64_t col_tiles = (N + ntc - 1) / ntc;
-  while ((spw + 1) * p.npad <= kSmallMaxN && small_lds_bytes(p.n, p.nnz, ntc, mode, dense, spw + 1) <= 160 * 1024 &&
+  while ((spw + 1) * p.npad <= kSmallMaxN && small_lds_bytes(p.n, p.nnz, C, ntc, mode, dense, spw + 1) <= 160 * 1024 &&
          (q + spw) / (spw + 1) * col_tiles >= 512)
     ++spw;
   p.spw = spw;
-  const size_t lds = small_lds_bytes(p.n, p.nnz, ntc, mode, dense, spw);
+  const size_t lds = small_lds_bytes(p.n, p.nnz, C, ntc, mode, dense, spw);
   const dim3 grid((unsigned)((q + spw - 1) / spw), (unsigned)col_tiles);
   hipStream_t st = (hipStream_t)stream;
   const unsigned nthreads = (unsigned)(p.npad * p.spw);
   ProfScope ps(TGCN_PROF_SMALL, st);
 #define TGCN_SMALL(NTCV, CPV)                                                                                     \
   {                                                                                                               \
-    static bool attr = false;                                                                                     \
-    if (!attr) { hipFuncSetAttribute((const void*)small_forward_kernel<NTCV, CPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    allow_large_lds((const void*)small_forward_kernel<NTCV, CPV>, 160 * 1024);                                      \
     hipLaunchKernelGGL((small_forward_kernel<NTCV, CPV>), grid, dim3(nthreads), lds, st, p);                      \
   }
   if (ntc == 16) { if (C <= 4) TGCN_SMALL(16, 4) else if (C <= 16) TGCN_SMALL(16, 16) else TGCN_SMALL(16, 32) }
   else { if (C <= 4) TGCN_SMALL(8, 4) else if (C <= 16) TGCN_SMALL(8, 16) else TGCN_SMALL(8, 32) }
 #undef TGCN_SMALL
   TGCN_CHECK_LAUNCH("tgcn_cheb_forward_small_f32");
+  return TGCN_OK;
+}
+
+int tgcn_cheb_basis_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode) {
+  int dense = 0;
+  return basis_config(n, nnz, C, mode, &dense);
+}
+
+int tgcn_cheb_basis_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C,
+                              const float* x, float* stack) {
+  if (!A || !x || !stack || K < 1 || q < 1 || C < 1) TGCN_FAIL(TGCN_ERR_INVALID, "basis_small: bad argument");
+  int dense = 0;
+  const int ct = basis_config(A->n, A->nnz, C, mode, &dense);
+  if (!ct) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "basis_small: n=%lld nnz=%lld does not fit in LDS", (long long)A->n, (long long)A->nnz);
+  if (K == 1) return TGCN_OK;
+  const int64_t col_tiles = (C + ct - 1) / ct;
+  if (q > 2147483647LL || col_tiles > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "basis_small: grid too large");
+  SmallParams p;
+  memset(&p, 0, sizeof(p));
+  p.rowptr = A->rowptr; p.ev = A->edges; p.x = x; p.out = stack;
+  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.mode = mode; p.dense = dense;
+  p.npad = (p.n + 63) / 64 * 64;
+  int spw = 1;
+  while ((spw + 1) * p.npad <= kSmallMaxN && basis_lds_bytes(p.n, p.nnz, ct, mode, dense, spw + 1) <= 160 * 1024 &&
+         (q + spw) / (spw + 1) * col_tiles >= 512)
+    ++spw;
+  p.spw = spw;
+  const size_t lds = basis_lds_bytes(p.n, p.nnz, ct, mode, dense, spw);
+  const dim3 grid((unsigned)((q + spw - 1) / spw), (unsigned)col_tiles);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nthreads = (unsigned)(p.npad * p.spw);
+  ProfScope ps(TGCN_PROF_SMALL_BASIS, st);
+#define TGCN_BASIS(CTV)                                                                    \
+  {                                                                                        \
+    allow_large_lds((const void*)small_basis_kernel<CTV>, 160 * 1024);                     \
+    hipLaunchKernelGGL((small_basis_kernel<CTV>), grid, dim3(nthreads), lds, st, p);       \
+  }
+  if (ct == 16) TGCN_BASIS(16) else if (ct == 8) TGCN_BASIS(8) else TGCN_BASIS(4)
+#undef TGCN_BASIS
+  TGCN_CHECK_LAUNCH("tgcn_cheb_basis_small_f32");
   return TGCN_OK;
 }
 

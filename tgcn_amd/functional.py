@@ -219,6 +219,27 @@ def cheb_forward_small(op, x3, W_kcn, fold, bias, bias_kind, mode):
     return out
 
 
+def small_basis_tile(op, C_row, mode):
+    """Channel tile of the one-launch basis kernel (weight gradient on small graphs), or 0 when the operand does not fit."""
+    if op.n_cols != op.n or not SMALL_PATH:
+        return 0
+    return _lib.lib().tgcn_cheb_basis_small_supported(op.n, op.nnz, int(C_row), int(mode))
+
+
+def cheb_basis_small(op, x3, K, mode):
+    """Terms of the layer's basis as a list of K (q, n, C) tensors (term 0 is x3 itself): monomials L^k x for
+    MODE_POWER (the basis of the folded weight), Chebyshev T_k x for MODE_CHEBYSHEV.  One launch."""
+    _lib.require_device(x3)
+    q, n, Crow = x3.shape
+    if K == 1:
+        return [x3]
+    stack = torch.empty((K - 1, q, n, Crow), dtype=torch.float32, device=x3.device)
+    # the kernel indexes terms k = 1 .. K-1 of a (K, q, n, C) stack: pass the address term 0 would have
+    base = stack.data_ptr() - q * n * Crow * 4
+    _lib.check(_lib.lib().tgcn_cheb_basis_small_f32(_lib.stream_ptr(), C.byref(op.struct), mode, K, q, Crow, _lib.ptr(x3), base))
+    return [x3] + [stack[k] for k in range(K - 1)]
+
+
 def cheb_forward_pf(op, x3, Wt_kcn, bias, bias_kind, mode):
     """Project-first form (tgcn_cheb_forward_pf_f32): ONE projection x . [W_0 | ... | W_{K-1}], then Horner / Clenshaw
     on the (q, n, N) results.  Wt_kcn: (K, C, N), already folded for MODE_POWER."""
@@ -251,7 +272,7 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     K, Crow, N = W.shape
     if small_path_tile(op, Crow, mode):
         return cheb_forward_small(op, x3, W, fold, b, bias_kind, mode)
-    Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W
+    Wt = torch.mm(fold.t(), W.reshape(K, Crow * N)).view(K, Crow, N) if fold is not None else W
     if use_project_first(x3.shape[0], x3.shape[1], Crow, N):
         return cheb_forward_pf(op, x3, Wt, b, bias_kind, mode)
     return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
@@ -299,20 +320,29 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs):
     """Gradients of the layer w.r.t. (x3, W, bias).  All contractions run in libtgcn_hip.so: the basis is recomputed
     with the hop kernel, dW is the MFMA weight-gradient kernel, G = g W^T is the projection kernel with the transposed
     weight, dx is Horner (mode 0) / Clenshaw (mode 1) on L^T with the hop kernel; only the bias reduction and the
-    K x K fold of the weight gradient are torch ops."""
-    Wt = torch.einsum("kj,kcn->jcn", fold, W) if fold is not None else W      # the basis the kernels work in
-    K, Crow, N = Wt.shape
+    K x K fold of the weight gradient are torch ops.  Graphs that fit in LDS take two one-launch kernels instead of the
+    2(K-1) hops: the basis kernel for dW and the forward kernel on L^T for dx."""
+    K, Crow, N = W.shape
     q, n, _ = x3.shape
+    Wt = W                                                            # the basis the kernels work in
+    if fold is not None and needs[0]:
+        Wt = torch.mm(fold.t(), W.reshape(K, Crow * N)).view(K, Crow, N)
     g = g.contiguous()
     g2d = g.reshape(q * n, N)
     gx = gW = gb = None
     if needs[1]:
         x3c = x3.contiguous()
-        basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
+        if small_basis_tile(op, Crow, mode):                          # small graphs: the whole basis in one launch
+            basis = cheb_basis_small(op, x3c, K, mode)
+        else:
+            basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
         gW = cheb_wgrad([basis[k].reshape(q * n, Crow) for k in range(K)], g2d)
         if fold is not None:                                          # back to the reference basis
-            gW = torch.einsum("kj,jcn->kcn", fold, gW)
-    if needs[0]:
+            gW = torch.mm(fold, gW.view(K, Crow * N)).view(K, Crow, N)
+    if needs[0] and small_path_tile(op.transpose(), N, mode):
+        # small graphs: dx = sum_j (L^T)^j g W_j^T is the one-launch forward kernel on (L^T, g, W^T)
+        gx = cheb_forward_small(op.transpose(), g, Wt.permute(0, 2, 1).contiguous(), None, None, BIAS_NONE, mode)
+    elif needs[0]:
         opT = op.transpose()
         # G[m, k*C + c] = sum_n g[m, n] W[k, c, n]: one projection with the (N, K*C) transposed weight
         Wcat = Wt.permute(2, 0, 1).reshape(1, N, K * Crow).contiguous()
