@@ -30,7 +30,7 @@ extern "C" {
 #define TGCN_ERR_WORKSPACE (-3)   /* caller workspace too small */
 #define TGCN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
 
-#define TGCN_ABI_VERSION 1
+#define TGCN_ABI_VERSION 2
 
 /* One stored entry of the sparse operand: 8 bytes, read with a single load. */
 typedef struct tgcn_edge {
@@ -45,6 +45,9 @@ typedef struct tgcn_csr {
   int64_t nnz;           /* < 2^31 */
   const int32_t* rowptr; /* [n+1] */
   const tgcn_edge* edges; /* [nnz], rows in order */
+  const float* dense;    /* optional (null if absent): the same operand as a row-major n x n fp32 matrix, duplicates
+                            summed.  Only read for small dense operands (n <= 256 with >= n*n/4 stored entries), which
+                            then run on the matrix pipe (tgcn_cheb_forward_small_f32 / tgcn_cheb_basis_small_f32). */
 } tgcn_csr;
 
 /* Work schedule of one operand for one lane-group width (built once by the host side, tgcn_amd/graph.py).
@@ -178,8 +181,12 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
  * graphs): the whole layer in ONE launch, recursion run on the output side in LDS (Horner for mode 0, Clenshaw for
  * mode 1).  W: (K, C, N) contiguous; `fold` (nullable, device, K x K): the reference_power -> monomial fold matrix,
  * applied while the weight is staged so the caller passes the layer's raw weight.
- * tgcn_cheb_forward_small_supported returns the channel tile (16 / 8) or 0 when the shape does not fit. */
-int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode);
+ * tgcn_cheb_forward_small_supported returns the channel tile (16 / 8) or 0 when the shape does not fit.
+ * Operands that store at least a quarter of their entries (n <= 256, C <= 32: the 148-parcel DTI graph of load/res) run
+ * the same recursion on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), L held as A-fragments in registers;
+ * tgcn_set_tuning("small_dense", 0) keeps them on the vector-ALU kernel. */
+int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode);   /* counts on A->dense for dense operands */
+int tgcn_cheb_forward_small_pool_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode);   /* ... with the fused relu + pool epilogue */
 int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
                                 const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
                                 float* out);

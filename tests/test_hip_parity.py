@@ -342,6 +342,50 @@ def test_small_basis_kernel_vs_oracle(n, q, C, K, gpu_device):
             assert rel_err(terms[k].cpu().numpy(), ref[k]) <= TOL, (mode, k)
 
 
+@pytest.mark.parametrize("n,q,Crow,N,K", [(148, 9, 15, 32, 10), (200, 5, 32, 40, 4), (256, 3, 8, 16, 5), (40, 700, 5, 7, 3), (100, 2, 1, 64, 2), (130, 3, 4, 4, 1)])
+def test_small_dense_operand_on_matrix_pipe(n, q, Crow, N, K, gpu_device):
+    """Dense small operands (>= 1/4 of the entries stored, n <= 256, C <= 32) run the one-launch layer and the basis on
+    the fp32 MFMA: against the oracle, both modes, all bias kinds, in-kernel fold, and against the vector-ALU kernels."""
+    from tgcn_amd import functional as F, _lib
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(n + K)
+    row, col, val = _random_graph(n, max(n * 2 // 3, 12), rng, isolated=(0, 9))
+    val = val * 0.5
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    assert op.nnz * 4 >= n * n
+    L = O.coo_to_csr(row, col, val, n).astype(np.float64)
+    x = rng.standard_normal((q, n, Crow)).astype(np.float32)
+    W = (rng.standard_normal((K, Crow, N)) / np.sqrt(K * Crow)).astype(np.float32)
+    fold = F.power_fold_matrix(K, "cuda")
+    for kind, bias in ((0, None), (1, rng.standard_normal(N).astype(np.float32)), (2, rng.standard_normal((n, N)).astype(np.float32))):
+        for mode in (F.MODE_POWER, F.MODE_CHEBYSHEV):
+            if mode == F.MODE_POWER:
+                basis = O.stack_reference_power(L, x.astype(np.float64), K)
+            else:
+                basis = O.stack_chebyshev(L, x.astype(np.float64), K)
+            ref = np.einsum("kqnc,kcg->qng", basis, W.astype(np.float64)) + (0 if bias is None else bias)
+            args = (op, _dev(x), _dev(W), fold if mode == F.MODE_POWER else None, None if bias is None else _dev(bias), kind, mode)
+            out = F.cheb_forward_small(*args)
+            assert rel_err(out.cpu().numpy(), ref) <= TOL, (kind, mode)
+            _lib.check(_lib.lib().tgcn_set_tuning(b"small_dense", 0))
+            try:
+                out_valu = F.cheb_forward_small(*args) if F.small_path_tile(op, Crow, mode) else None   # n > ~190 does not fit it
+            finally:
+                _lib.check(_lib.lib().tgcn_set_tuning(b"small_dense", 1))
+            assert out_valu is None or rel_err(out.cpu().numpy(), out_valu.cpu().numpy()) <= TOL
+    for mode in (F.MODE_POWER, F.MODE_CHEBYSHEV):
+        if mode == F.MODE_POWER:
+            P = [x.astype(np.float64)]
+            for _ in range(1, K):
+                P.append(O._apply(L, P[-1]))
+            ref = np.stack(P)
+        else:
+            ref = O.stack_chebyshev(L, x.astype(np.float64), K)
+        terms = F.cheb_basis_small(op, _dev(x), K, mode)
+        for k in range(K):
+            assert rel_err(terms[k].cpu().numpy(), ref[k]) <= TOL, (mode, k)
+
+
 @pytest.mark.parametrize("n,q,Crow,N,K", [(784, 5, 28, 64, 5), (300, 3, 1, 8, 5), (1000, 2, 32, 15, 3), (64, 7, 12, 70, 10), (500, 2, 5, 16, 1),
                                           (200, 3, 17, 33, 25), (784, 2, 64, 28, 5), (300, 3, 40, 7, 4), (148, 4, 100, 12, 3), (100, 2, 33, 16, 6)])
 def test_small_graph_kernel_vs_oracle(n, q, Crow, N, K, gpu_device):

@@ -16,7 +16,7 @@ class TgcnError(RuntimeError):
 
 
 class CsrStruct(C.Structure):
-    _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edges", C.c_void_p)]
+    _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edges", C.c_void_p), ("dense", C.c_void_p)]
 
 
 class SchedStruct(C.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
                                         C.c_int32, C.c_int64, _P, C.c_size_t]),
     "tgcn_cheb_forward_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_basis_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_cheb_forward_small_pool_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_basis_small_f32": (C.c_int, [C.c_void_p, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                            C.c_void_p, C.c_void_p]),
     "tgcn_cheb_forward_small_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
@@ -106,7 +107,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.tgcn_abi_version() != 1:
+        if handle.tgcn_abi_version() != 2:
             raise TgcnError("tgcn_amd: ABI version mismatch")
         _lib = handle
     return _lib

@@ -375,7 +375,8 @@ inline void allow_large_lds(const void* fn, int bytes) {
 
 std::atomic<int> g_hop_variant{0};
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
-std::atomic<int> g_overlap{0};        // layer driver: projection of pass i on a side stream under the hops of pass i+1
+std::atomic<int> g_overlap{0};
+std::atomic<int> g_small_dense{1};     // small dense operands on the fp32 matrix pipe (0: vector-ALU kernels only)        // layer driver: projection of pass i on a side stream under the hops of pass i+1
 
 struct SideStream { hipStream_t st = nullptr; hipEvent_t hops_done[2] = {nullptr, nullptr}; hipEvent_t proj_done[2] = {nullptr, nullptr}; };
 std::mutex g_side_mu;
@@ -1218,6 +1219,7 @@ inline int small_cpad(int C) { return C <= 4 ? 4 : (C <= 16 ? 16 : (C + 31) / 32
 struct SmallParams {
   const int32_t* rowptr;
   const tgcn_edge* ev;
+  const float* Ld;     // dense n x n copy of the operand (small_dense_kernel), nullable
   const float* x;
   const float* W;      // (K, C, N)
   const float* fold;   // (K, K) or null: W'_j = sum_k fold[k][j] W_k applied while staging (mode 0)
@@ -1587,6 +1589,214 @@ inline int basis_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int* de
   return 0;
 }
 
+// ---- small DENSE operands (the 148-parcel DTI graph of load/res: 34 % of the entries stored) on the fp32 matrix pipe.
+// Same recursions as small_forward_kernel / small_basis_kernel, but L . Y is a dense (npad x npad) x (npad x S*16)
+// product per step:  one wave per 16-row tile of L, whose A-fragments (npad/4 registers, read from the dense copy
+// tgcn_csr.dense) stay in registers for the whole kernel; Y (S samples x 16 channels per workgroup) lives in LDS with a row stride of S*16+16 floats (the four
+// k rows of a B-fragment read fall into different banks).  v_mfma_f32_16x16x4_f32: k-ordered fp32 fmaf chain.
+//   A lane (r = lane&15, kq = lane>>4) = A[row r][k kq];  B = B[k kq][col r];  D[i] = D[row 4*kq+i][col r].
+constexpr int kDenseMaxN = 256;      // vertices (16 row tiles -> 16 waves)
+constexpr int kDenseMaxC = 32;       // input row length (X fragments in registers)
+constexpr int kDenseWFloats = 4096;  // LDS for weight tiles: all K of them when they fit (staged once), else one per step
+template <int S, bool BASIS, int NW>   // NW: most waves (16-row tiles) of a workgroup -> register budget and size of Lf
+__global__ __launch_bounds__(NW * 64) void small_dense_kernel(const SmallParams p) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int LDY = S * 16 + 16;
+  constexpr int NKMAX = NW * 4, XKMAX = kDenseMaxC / 4;
+  constexpr int kDenseKB = 8 / S;                        // k-steps of B fragments per batch (8 LDS reads in flight)
+  const int n = p.n, C = p.C;
+  const int npad = (n + 15) / 16 * 16, nk = npad / 4;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int i0 = wave * 16;                              // this wave's row tile
+  const int nbuf = p.mode == 0 ? 2 : 3;
+  const int cpad = (C + 3) / 4 * 4, xk = cpad / 4;
+  float* Wt = smem;                                      // (cpad, 16) weight tile of the step (not for BASIS)
+  float* Ybase = smem + (BASIS ? 0 : kDenseWFloats);     // nbuf buffers of npad x LDY
+  const bool w_all = !BASIS && p.K * cpad * 16 <= kDenseWFloats;
+  const int q0 = blockIdx.x * S, n0 = blockIdx.y * 16;   // first sample; first output channel (BASIS: input channel)
+
+  // ---- L fragments straight from the dense copy of the operand (L2-resident: every workgroup reads the same 4 n^2 bytes)
+  float Lf[NKMAX];
+#pragma unroll
+  for (int kt = 0; kt < NKMAX; ++kt) {
+    const int row = i0 + r, col = kt * 4 + kq;
+    Lf[kt] = (kt < nk && row < n && col < n) ? p.Ld[(int64_t)row * n + col] : 0.f;
+  }
+  // ---- X fragments (forward: the wave's 16 input rows of every sample) / initial Y = x tile (basis)
+  float Xf[BASIS ? 1 : S][BASIS ? 1 : XKMAX];
+  if constexpr (!BASIS) {
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int kt = 0; kt < XKMAX; ++kt) {
+        const int c = kt * 4 + kq, i = i0 + r;
+        Xf[s][kt] = (q0 + s < p.q && i < n && c < C) ? p.x[((int64_t)(q0 + s) * n + i) * C + c] : 0.f;
+      }
+  } else {
+    for (int e = tid; e < npad * S * 16; e += nthr) {
+      const int i = e / (S * 16), sc = e % (S * 16), s = sc >> 4, c = n0 + (sc & 15);
+      Ybase[i * LDY + sc] = (q0 + s < p.q && i < n && c < C) ? p.x[((int64_t)(q0 + s) * n + i) * C + c] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  auto stage_w = [&](float* dst, int j) {                 // (cpad, 16) tile of W'_j: rows c >= C and columns >= N are zero
+    for (int e = tid; e < cpad * 16; e += nthr) {
+      const int c = e >> 4, g = e & 15;
+      float w = 0.f;
+      if (c < C && n0 + g < p.N) {
+        if (p.fold) {
+          for (int k = 0; k < p.K; ++k) w = fmaf(p.fold[k * p.K + j], p.W[((int64_t)k * C + c) * p.N + n0 + g], w);
+        } else {
+          w = p.W[((int64_t)j * C + c) * p.N + n0 + g];
+        }
+      }
+      dst[e] = w;
+    }
+  };
+  if constexpr (!BASIS) {
+    if (w_all) {
+      for (int j = 0; j < p.K; ++j) stage_w(Wt + j * cpad * 16, j);
+      __syncthreads();
+    }
+  }
+  int cur = BASIS ? 1 : 0;
+  const int nsteps = BASIS ? p.K - 1 : p.K;
+  for (int st = 0; st < nsteps; ++st) {
+    const int j = BASIS ? st + 1 : p.K - 1 - st;         // basis: term being produced; forward: Horner / Clenshaw index
+    if constexpr (!BASIS) {
+      if (!w_all) {
+        stage_w(Wt, j);                                   // weight tile of this step
+        __syncthreads();
+      }
+    }
+    const float* Wj = w_all ? Wt + j * cpad * 16 : Wt;
+    const bool first = !BASIS && st == 0;
+    const float alpha = BASIS ? ((p.mode == 1 && j >= 2) ? 2.f : 1.f) : ((p.mode == 1 && j > 0) ? 2.f : 1.f);
+    const bool sub = p.mode == 1 && (BASIS ? j >= 2 : j <= p.K - 3);
+    const float* B1 = Ybase + ((cur + nbuf - 1) % nbuf) * npad * LDY;
+    const float* B2 = Ybase + ((cur + nbuf - 2) % nbuf) * npad * LDY;
+    float* Yn = Ybase + cur * npad * LDY;
+    f32x4 acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+      // fully unrolled (Lf stays in registers); B fragments are read kDenseKB k-steps ahead of the MFMAs that use them
+      float bb[2][kDenseKB][S];
+#pragma unroll
+      for (int u = 0; u < kDenseKB; ++u)
+#pragma unroll
+        for (int s = 0; s < S; ++s) bb[0][u][s] = u < nk ? B1[(u * 4 + kq) * LDY + r + s * 16] : 0.f;
+#pragma unroll
+      for (int kt0 = 0; kt0 < NKMAX; kt0 += kDenseKB) {
+        if (kt0 < nk) {
+          const int b = (kt0 / kDenseKB) & 1;
+          if (kt0 + kDenseKB < nk) {
+#pragma unroll
+            for (int u = 0; u < kDenseKB; ++u)
+#pragma unroll
+              for (int s = 0; s < S; ++s)
+                bb[b ^ 1][u][s] = kt0 + kDenseKB + u < nk ? B1[((kt0 + kDenseKB + u) * 4 + kq) * LDY + r + s * 16] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < kDenseKB; ++u) {
+            if (kt0 + u < nk) {
+#pragma unroll
+              for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(Lf[kt0 + u], bb[b][u][s], acc[s], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = alpha * acc[s][i];
+          if (sub) v = fmaf(alpha, acc[s][i], -B2[(i0 + kq * 4 + i) * LDY + s * 16 + r]);
+          acc[s][i] = v;
+        }
+    }
+    if constexpr (!BASIS) {
+#pragma unroll
+      for (int kt = 0; kt < XKMAX; ++kt) {
+        if (kt < xk) {
+          const float wv = Wj[(kt * 4 + kq) * 16 + r];
+#pragma unroll
+          for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xf[s][kt], wv, acc[s], 0, 0, 0);
+        }
+      }
+    }
+    const bool last = st == nsteps - 1;
+    if (!last) {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Yn[(i0 + kq * 4 + i) * LDY + s * 16 + r] = acc[s][i];
+    }
+    if (BASIS || last) {                                  // basis: every term goes out; forward: the last step + bias
+      const int ch = n0 + r;
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i0 + kq * 4 + i;
+          if (q0 + s >= p.q || row >= n) continue;
+          if constexpr (BASIS) {
+            if (ch < C) p.out[(((int64_t)j * p.q + q0 + s) * n + row) * C + ch] = acc[s][i];
+          } else {
+            if (ch < p.N) {
+              float v = acc[s][i];
+              if (p.bias_kind == 1) v += p.bias[ch];
+              else if (p.bias_kind == 2) v += p.bias[(int64_t)row * p.N + ch];
+              p.out[((int64_t)(q0 + s) * n + row) * p.N + ch] = v;
+            }
+          }
+        }
+    }
+    __syncthreads();
+    cur = (cur + 1) % nbuf;
+  }
+}
+
+// samples per workgroup (4 / 2 / 1) of small_dense_kernel, 0 when the shape is not for it
+inline int dense_mfma_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int64_t q, int64_t col_tiles, bool basis) {
+  if (n < 16 || n > kDenseMaxN || (!basis && C > kDenseMaxC) || (mode != 0 && mode != 1)) return 0;
+  if (nnz * 4 < n * n) return 0;                       // at least a quarter of the entries stored: dense arithmetic pays
+  const int npad = (int)(n + 15) / 16 * 16;
+  const int nbuf = mode == 0 ? 2 : 3;
+  const int nw = npad / 16;            // register budget per lane shrinks with the wave count: fewer samples (accumulators)
+  const int smax = basis ? (nw > 12 ? 2 : 4) : (nw > 12 ? 1 : (nw > 8 ? 2 : 4));
+  for (int S = smax; S >= 1; S /= 2) {
+    const size_t fl = (size_t)(basis ? 0 : kDenseWFloats) + (size_t)nbuf * npad * (S * 16 + 16);
+    if (fl * sizeof(float) > 160 * 1024) continue;
+    if (S > 1 && (q + S - 1) / S * col_tiles < 192) continue;                         // keep most CUs busy
+    return S;
+  }
+  return 0;
+}
+
+template <bool BASIS>
+inline void launch_small_dense(hipStream_t st, const SmallParams& p, int S, int64_t col_tiles) {
+  const int npad = (p.n + 15) / 16 * 16;
+  const int nbuf = p.mode == 0 ? 2 : 3;
+  const size_t lds = ((size_t)(BASIS ? 0 : kDenseWFloats) + (size_t)nbuf * npad * (S * 16 + 16)) * sizeof(float);
+  const dim3 grid((unsigned)((p.q + S - 1) / S), (unsigned)col_tiles);
+  const dim3 block((unsigned)(npad / 16 * 64));
+#define TGCN_DENSE(SV, NWV)                                                                  \
+  {                                                                                          \
+    allow_large_lds((const void*)small_dense_kernel<SV, BASIS, NWV>, 160 * 1024);            \
+    hipLaunchKernelGGL((small_dense_kernel<SV, BASIS, NWV>), grid, block, lds, st, p);       \
+  }
+#define TGCN_DENSE_S(NWV) \
+  if (S == 4) TGCN_DENSE(4, NWV) else if (S == 2) TGCN_DENSE(2, NWV) else TGCN_DENSE(1, NWV)
+  const int nw = npad / 16;
+  if (nw <= 8) { TGCN_DENSE_S(8) } else if (nw <= 12) { TGCN_DENSE_S(12) } else { TGCN_DENSE_S(16) }
+#undef TGCN_DENSE_S
+#undef TGCN_DENSE
+}
+
 // --------------------------------------------------------------------------------------------------
 // relayout (Q,n,C) -> (n,Q,C), C <= 32
 // --------------------------------------------------------------------------------------------------
@@ -1696,6 +1906,7 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
   if (key && strcmp(key, "overlap") == 0) { g_overlap.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
 }
@@ -2010,9 +2221,16 @@ static void fwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t
   *total = o;
 }
 
-int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode) {
+int tgcn_cheb_forward_small_pool_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode) {
   int dense = 0;
   return small_config(n, nnz, C, mode, &dense);
+}
+
+int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode) {
+  int dense = 0;
+  const int ntc = small_config(n, nnz, C, mode, &dense);
+  if (ntc) return ntc;
+  return (g_small_dense.load() && dense_mfma_config(n, nnz, C, mode, 1, 1, false)) ? 16 : 0;
 }
 
 int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C, int32_t N,
@@ -2028,13 +2246,29 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
   if (pool < 0 || pool > 255 || (pool > 0 && A->n % pool != 0) || (pool == 0 && relu)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: pool=%d relu=%d n=%lld", pool, relu, (long long)A->n);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bias_kind %d", bias_kind);
   if (fold && mode != 0) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: fold is for mode 0");
+  if (q > 2147483647LL) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: grid too large");
   int dense = 0;
-  const int ntc = small_config(A->n, A->nnz, C, mode, &dense);
-  if (!ntc) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: n=%lld nnz=%lld C=%d does not fit in LDS", (long long)A->n, (long long)A->nnz, C);
-  if (q > 2147483647LL || (N + ntc - 1) / ntc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: grid too large");
   SmallParams p;
   p.rowptr = A->rowptr; p.ev = A->edges; p.x = x; p.W = W; p.fold = fold; p.bias = bias; p.out = out;
-  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.N = N; p.mode = mode; p.bias_kind = bias_kind; p.dense = dense; p.relu = relu; p.pool = pool; p.pool_idx = pool_idx;
+  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.N = N; p.mode = mode; p.bias_kind = bias_kind; p.dense = 0; p.relu = relu; p.pool = pool; p.pool_idx = pool_idx;
+  p.npad = 0; p.spw = 1;
+  p.Ld = A->dense;
+  if (pool == 0 && A->dense && g_small_dense.load()) {   // dense operand (e.g. the 148-parcel DTI graph): fp32 matrix pipe
+    const int64_t tiles16 = (N + 15) / 16;
+    const int S = dense_mfma_config(A->n, A->nnz, C, mode, q, tiles16, false);
+    if (S && tiles16 <= 65535) {
+      p.npad = 0; p.spw = S;
+      hipStream_t st = (hipStream_t)stream;
+      ProfScope ps(TGCN_PROF_SMALL, st);
+      launch_small_dense<false>(st, p, S, tiles16);
+      TGCN_CHECK_LAUNCH("tgcn_cheb_forward_small_f32 (dense)");
+      return TGCN_OK;
+    }
+  }
+  const int ntc = small_config(A->n, A->nnz, C, mode, &dense);
+  if (!ntc) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: n=%lld nnz=%lld C=%d does not fit in LDS", (long long)A->n, (long long)A->nnz, C);
+  if ((N + ntc - 1) / ntc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: grid too large");
+  p.dense = dense;
   // samples per workgroup: as many as fit the 1024-thread / 160 KB budget, but keep >= 512 workgroups in the grid
   p.npad = (p.n + 63) / 64 * 64;
   int spw = 1;
@@ -2062,22 +2296,40 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
 
 int tgcn_cheb_basis_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode) {
   int dense = 0;
-  return basis_config(n, nnz, C, mode, &dense);
+  const int ct = basis_config(n, nnz, C, mode, &dense);
+  if (ct) return ct;
+  return (g_small_dense.load() && dense_mfma_config(n, nnz, C, mode, 1, 1, true)) ? 16 : 0;
 }
 
 int tgcn_cheb_basis_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int32_t K, int64_t q, int32_t C,
                               const float* x, float* stack) {
   if (!A || !x || !stack || K < 1 || q < 1 || C < 1) TGCN_FAIL(TGCN_ERR_INVALID, "basis_small: bad argument");
-  int dense = 0;
-  const int ct = basis_config(A->n, A->nnz, C, mode, &dense);
-  if (!ct) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "basis_small: n=%lld nnz=%lld does not fit in LDS", (long long)A->n, (long long)A->nnz);
+  if (!tgcn_cheb_basis_small_supported(A->n, A->nnz, C, mode))
+    TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "basis_small: n=%lld nnz=%lld does not fit in LDS", (long long)A->n, (long long)A->nnz);
   if (K == 1) return TGCN_OK;
-  const int64_t col_tiles = (C + ct - 1) / ct;
-  if (q > 2147483647LL || col_tiles > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "basis_small: grid too large");
+  if (q > 2147483647LL || C > 16 * 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "basis_small: grid too large");
   SmallParams p;
   memset(&p, 0, sizeof(p));
   p.rowptr = A->rowptr; p.ev = A->edges; p.x = x; p.out = stack;
-  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.mode = mode; p.dense = dense;
+  p.n = (int32_t)A->n; p.nnz = (int32_t)A->nnz; p.q = (int32_t)q; p.K = K; p.C = C; p.mode = mode;
+  p.Ld = A->dense;
+  if (A->dense && g_small_dense.load()) {
+    const int64_t tiles16 = (C + 15) / 16;
+    const int S = dense_mfma_config(A->n, A->nnz, C, mode, q, tiles16, true);
+    if (S) {
+      p.spw = S;
+      hipStream_t st = (hipStream_t)stream;
+      ProfScope ps(TGCN_PROF_SMALL_BASIS, st);
+      launch_small_dense<true>(st, p, S, tiles16);
+      TGCN_CHECK_LAUNCH("tgcn_cheb_basis_small_f32 (dense)");
+      return TGCN_OK;
+    }
+  }
+  int dense = 0;
+  const int ct = basis_config(A->n, A->nnz, C, mode, &dense);
+  if (!ct) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "basis_small: n=%lld nnz=%lld does not fit in LDS", (long long)A->n, (long long)A->nnz);
+  const int64_t col_tiles = (C + ct - 1) / ct;
+  p.dense = dense;
   p.npad = (p.n + 63) / 64 * 64;
   int spw = 1;
   while ((spw + 1) * p.npad <= kSmallMaxN && basis_lds_bytes(p.n, p.nnz, ct, mode, dense, spw + 1) <= 160 * 1024 &&

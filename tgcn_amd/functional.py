@@ -201,11 +201,13 @@ def _power_fold_matrix(K, device=None, dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------------------- autograd
-def small_path_tile(op, C_row, mode):
-    """Channel tile (16 / 8) of the one-launch LDS-resident kernel, or 0 when the shape does not fit it."""
+def small_path_tile(op, C_row, mode, pool=False):
+    """Channel tile (16 / 8) of the one-launch LDS-resident kernel, or 0 when the shape does not fit it
+    (pool: with the fused relu + pool epilogue)."""
     if op.n_cols != op.n or not SMALL_PATH:
         return 0
-    return _lib.lib().tgcn_cheb_forward_small_supported(op.n, op.nnz, int(C_row), int(mode))
+    fn = _lib.lib().tgcn_cheb_forward_small_pool_supported if pool else _lib.lib().tgcn_cheb_forward_small_supported
+    return fn(op.n, op.nnz, int(C_row), int(mode))
 
 
 def cheb_forward_small(op, x3, W_kcn, fold, bias, bias_kind, mode):
@@ -387,7 +389,7 @@ class ChebReluPoolFn(torch.autograd.Function):
         z = torch.empty((q, n // pool, N), dtype=torch.float32, device=x3.device)
         idx = torch.empty((q, n // pool, N), dtype=torch.uint8, device=x3.device)
         L = _lib.lib()
-        if small_path_tile(op, Crow, mode):
+        if small_path_tile(op, Crow, mode, pool=True):
             _lib.check(L.tgcn_cheb_forward_small_pool_f32(_lib.stream_ptr(), C.byref(op.struct), mode, K, q, Crow, N, _lib.ptr(x3),
                                                           _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
                                                           _lib.ptr(z), _lib.ptr(idx)))

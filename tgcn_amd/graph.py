@@ -15,6 +15,7 @@ SEG_LEN = 32            # stored entries per segment (measured on cfg5: 32 beats
 SEG_KEY = "first"       # column of the segment used as its place in the processing order
 HUGE_SLOTS = 64         # long rows with more segments than this get a whole workgroup in the fix-up
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
+DENSE_MAX_N = 256       # operands up to this size that store >= 1/4 of their entries also keep a dense copy
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
 
 
@@ -116,7 +117,14 @@ class GraphOperand:
             edges[:, 0] = col
             edges[:, 1] = val.view(torch.int32)
         self.edges = edges
-        self.struct = _lib.CsrStruct(self.n, self.nnz, self.rowptr.data_ptr(), self.edges.data_ptr())
+        # small dense operands (the 148-parcel DTI graph of load/res): a dense copy for the matrix-pipe kernels
+        self.dense = None
+        if self.n_cols == self.n and 16 <= self.n <= DENSE_MAX_N and self.nnz * 4 >= self.n * self.n:
+            counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), counts)
+            self.dense = torch.sparse_coo_tensor(torch.stack([rows, col.to(torch.int64)]), val, (self.n, self.n)).coalesce().to_dense().contiguous()
+        self.struct = _lib.CsrStruct(self.n, self.nnz, self.rowptr.data_ptr(), self.edges.data_ptr(),
+                                     self.dense.data_ptr() if self.dense is not None else None)
         self._sched = {}
         self._transpose = None
 
