@@ -129,7 +129,8 @@ def main():
     ap.add_argument("--vertices", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
     ap.add_argument("--entries", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--shard", default="time", choices=["time", "vertex"], help="N > 1: time steps per rank (no collective, weak scaling) or vertex rows per rank with a halo / all-gather exchange per hop (strong scaling)")
+    ap.add_argument("--shard", default="time", choices=["time", "vertex", "hybrid"], help="N > 1: time steps per rank (no collective, weak scaling); vertex rows per rank with a halo / all-gather exchange per hop (strong scaling); hybrid: --vertex-shards ranks share a graph, groups split the time steps")
+    ap.add_argument("--vertex-shards", type=int, default=2, help="ranks per graph copy for --shard hybrid")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--project-variant", type=int, default=None, help="developer: tgcn_set_tuning(project_variant, v)")
     ap.add_argument("--no-small-path", action="store_true", help="developer: disable the one-launch small-graph kernel")
@@ -157,22 +158,28 @@ def main():
         _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", args.project_variant))
     op, spec = build_workload(args.workload, args.labeling, device, args.vertices, args.entries)
     K, q, H = spec["K"], spec["q"], spec["H"]
-    vertex_mode = world > 1 and args.shard == "vertex"
+    vertex_mode = world > 1 and args.shard in ("vertex", "hybrid")
+    ngroups = 1
     if vertex_mode:
         # every rank holds the same seeded graph; rank r owns an nnz-balanced row range and its slice of x / bias
-        from tgcn_amd.dist import VertexShardedCheb
-        assert spec["cls"] == "TGCNCheb", "vertex sharding bench is wired for the cfg5 layer"
+        # (hybrid: inside its group of --vertex-shards ranks; the groups take different time steps, no communication)
+        from tgcn_amd.dist import VertexShardedCheb, hybrid_groups
+        assert spec["cls"] in ("TGCNCheb", "TGCNCheb_H"), "vertex sharding bench is wired for the cfg5 / cfg4 layers"
+        group = None
+        if args.shard == "hybrid":
+            group, _, ngroups = hybrid_groups(world, args.vertex_shards)
         row, col, val = op.coo()
-        sh = VertexShardedCheb(op.n, row, col, val, device=device, exchange="auto")
+        sh = VertexShardedCheb(op.n, row, col, val, group=group, device=device, exchange="auto")
         del row, col, val
         torch.manual_seed(1)
         import tgcn_amd
-        Wraw = torch.empty(K, spec["f"], spec["g"], device=device)
-        tgcn_amd.uniform(spec["f"] * K, Wraw)
+        C_in = spec["H"] * spec["f"]                       # TGCNCheb_H: the H time steps of a window are the row
+        Wraw = torch.empty(K, C_in, spec["g"], device=device)
+        tgcn_amd.uniform(C_in * K, Wraw)
         Wf = torch.einsum("kj,kcn->jcn", _F.power_fold_matrix(K, device), Wraw).contiguous()
         bias_local = torch.zeros(sh.owned, spec["g"], device=device)
         g = torch.Generator(device=device).manual_seed(rank)
-        x_local = torch.randn((q, sh.owned, spec["f"]), device=device, generator=g)
+        x_local = torch.randn((q, sh.owned, C_in), device=device, generator=g)
 
         class _Sharded:
             bias = None
@@ -206,7 +213,7 @@ def main():
         dt = float(tmax.item())
 
     units_per_step = op.nnz * (K - 1) * q * H            # edge.timesteps per forward per rank
-    value = (1 if vertex_mode else world) * units_per_step * args.steps / dt / 1e9   # vertex mode: ONE graph over all ranks
+    value = (ngroups if vertex_mode else world) * units_per_step * args.steps / dt / 1e9   # vertex mode: ONE graph per group of ranks
 
     # ---- roofline of the dominant kernel (hop_kernel): algorithmic bytes per launch / mean launch duration
     hop_ms = [ms for kind, ms in prof if kind == 0]
@@ -261,10 +268,10 @@ def main():
     if rank == 0:
         line = dict(metric="Cheb-TGCN fwd: G edge.timesteps/s + achieved HBM GB/s, K=5 on 160M-edge graph",
                     value=round(value, 3), unit="G edge.timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if vertex_mode else "weak", vs_baseline=None,
+                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if (vertex_mode and ngroups == 1) else "weak", vs_baseline=None,
                     dtype="f32", data="synthetic",
                     config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
-                                sharding=("vertex rows across ranks, %s exchange per hop" % sh.exchange) if vertex_mode else ("time steps across ranks, CSR replicated, no collective" if world > 1 else "single GPU"),
+                                sharding=(("%d group(s) x %d vertex shards, %s exchange per hop inside a group" % (ngroups, sh.world, sh.exchange)) if ngroups > 1 else ("vertex rows across ranks, %s exchange per hop" % sh.exchange)) if vertex_mode else ("time steps across ranks, CSR replicated, no collective" if world > 1 else "single GPU"),
                                 nnz=op.nnz, n=op.n),
                     roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line))

@@ -107,3 +107,45 @@ def test_vertex_sharded_matches_oracle(world, exchange, banded, mode):
         assert owned == 400 and cnt == 7
         if exchange == "auto" and not banded:
             assert used == "allgather"
+
+
+def _hybrid_worker(rank, world, port, exchange, banded, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tgcn_amd.dist import VertexShardedCheb, hybrid_groups, shard_time_steps
+        n, q, C, N, K = 300, 6, 4, 3, 4
+        row, col, val = _graph(n, 5, banded)
+        rng = np.random.default_rng(6)
+        x = rng.standard_normal((q, n, C)).astype(np.float32)
+        W = (rng.standard_normal((K, C, N)) / 4).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        group, gi, ng = hybrid_groups(world, 2)
+        sl = shard_time_steps(q, gi, ng)                       # this group's samples
+        sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), group=group, device="cpu",
+                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project)
+        out_local = sh.forward(torch.from_numpy(x[sl, sh.lo:sh.hi]), torch.from_numpy(W), torch.from_numpy(bias), 1, 1)
+        L = O.coo_to_csr(row, col, val, n)
+        ref = np.einsum("kqnc,kcg->qng", O.stack_chebyshev(L, x, K).astype(np.float64), W.astype(np.float64)) + bias
+        err = np.abs(out_local.numpy() - ref[sl, sh.lo:sh.hi]).max() / np.abs(ref).max()
+        ret[rank] = (float(err), gi, ng, sh.rank, sh.world, sl.start, sl.stop, sh.lo, sh.hi)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,banded", [("halo", True), ("allgather", False)])
+def test_hybrid_vertex_x_time_layout(exchange, banded):
+    """4 ranks = 2 time groups x 2 vertex shards: exchanges stay inside a group, groups never talk; together the ranks
+    cover every (sample, vertex) exactly once."""
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hybrid_worker, args=(world, _free_port(), exchange, banded, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    cover = np.zeros((6, 300), np.int32)
+    for rank in range(world):
+        err, gi, ng, vr, vw, s0, s1, lo, hi = ret[rank]
+        assert err <= 1e-5, (rank, err)
+        assert (gi, ng, vr, vw) == (rank // 2, 2, rank % 2, 2)
+        cover[s0:s1, lo:hi] += 1
+    assert np.all(cover == 1)

@@ -7,7 +7,8 @@ pytorch_hcp_tgcn.py:270-273).  The path shards two ways:
     sample, so ranks that hold the CSR need NO data-path communication (`shard_time_steps`; bench.py --gpus N);
   * by vertices: 1-D row partition of L-hat, X and out; one exchange of the previous hop's cut-edge neighbour
     rows per hop (`VertexShardedCheb`): point-to-point halo rows when the cut is small, an RCCL all-gather of the
-    owned row blocks when the halo is most of the graph (R-MAT).
+    owned row blocks when the halo is most of the graph (R-MAT);
+  * both at once (`hybrid_groups`): vertex shards inside a group of ranks, time steps across groups.
 
 The compute callables are injectable so the communication logic is testable with gloo on CPU against the oracle
 (tests/test_dist_gloo.py); the defaults are the HIP entry points.
@@ -21,6 +22,23 @@ def shard_time_steps(q, rank, world):
     base, extra = divmod(q, world)
     lo = rank * base + min(rank, extra)
     return slice(lo, lo + base + (1 if rank < extra else 0))
+
+
+def hybrid_groups(world, vertex_shards, rank=None):
+    """2-D layout of SURVEY.md section 8e: `vertex_shards` consecutive ranks share one copy of the graph (vertex
+    sharding, one exchange per hop inside the group) and the world // vertex_shards groups split the samples / time
+    steps between them with no communication.  Every rank must call this (new_group is collective).
+    -> (group of this rank, index of its group, number of groups)."""
+    if world % vertex_shards:
+        raise ValueError("world size %d is not a multiple of %d vertex shards" % (world, vertex_shards))
+    rank = dist.get_rank() if rank is None else rank
+    ngroups = world // vertex_shards
+    mine = None
+    for g in range(ngroups):
+        grp = dist.new_group(ranks=list(range(g * vertex_shards, (g + 1) * vertex_shards)))
+        if rank // vertex_shards == g:
+            mine = grp
+    return mine, rank // vertex_shards, ngroups
 
 
 def balanced_row_bounds(row, n, world):
@@ -64,6 +82,8 @@ class VertexShardedCheb:
                  hop_fn=_default_hop, project_fn=_default_project):
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # point-to-point peers are named by GLOBAL rank; inside a sub-group (hybrid layout) translate the group index
+        self.peer = [dist.get_global_rank(group, p) if group is not None else p for p in range(self.world)]
         self.device = torch.device(device) if device is not None else row.device
         self.hop_fn, self.project_fn = hop_fn, project_fn
         row, col, val = row.to(self.device), col.to(self.device), val.to(self.device)
@@ -117,9 +137,9 @@ class VertexShardedCheb:
                 if p == self.rank:
                     continue
                 if recvs[p] is not None:
-                    ops.append(dist.P2POp(dist.irecv, recvs[p], p, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, recvs[p], self.peer[p], group=self.group))
                 if sends[p] is not None:
-                    ops.append(dist.P2POp(dist.isend, sends[p], p, group=self.group))
+                    ops.append(dist.P2POp(dist.isend, sends[p], self.peer[p], group=self.group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
