@@ -376,6 +376,7 @@ inline void allow_large_lds(const void* fn, int bytes) {
 std::atomic<int> g_hop_variant{0};
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
 std::atomic<int> g_overlap{0};
+std::atomic<int> g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS
 std::atomic<int> g_small_dense{1};     // small dense operands on the fp32 matrix pipe (0: vector-ALU kernels only)        // layer driver: projection of pass i on a side stream under the hops of pass i+1
 
 struct SideStream { hipStream_t st = nullptr; hipEvent_t hops_done[2] = {nullptr, nullptr}; hipEvent_t proj_done[2] = {nullptr, nullptr}; };
@@ -828,6 +829,212 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + nt * 16 + col_l;
+        if (col >= p.N) continue;
+        float v = acc[r][nt][i];
+        if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+        else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+        float* o = p.out + orow * p.ldo + col;
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
+// ---- bf16x3, second form (16-byte aligned operands): a wave's A rows are used by that wave only, so its A fragments
+// go global -> registers -> split -> MFMA operand with no LDS round trip and no barrier; only the W tile (shared by the
+// 8 waves) is split into LDS, double-buffered, ONE barrier per 32-k tile.  A lane loads the 8 consecutive k of its row
+// as two float4 (the four k groups of a row are adjacent: whole 128-byte lines per row).
+template <int NT>
+__global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
+  constexpr int XT = 512, BM = 256, KT = 32, RS = KT;
+  constexpr int NW = NT * 16;
+  constexpr int WPAIRS = (KT / 2 * NW + XT - 1) / XT;
+  constexpr int WBUF = 3 * NW * RS;                                   // bf16 elements of one W buffer (3 planes)
+  constexpr int ES = NW + 4;                                          // epilogue scratch row stride (floats)
+  constexpr int LDS_BYTES = (2 * WBUF * 2 > 8 * 16 * ES * 4) ? 2 * WBUF * 2 : 8 * 16 * ES * 4;
+  __shared__ __align__(16) unsigned char lds_raw[LDS_BYTES];
+  unsigned short* Wp = reinterpret_cast<unsigned short*>(lds_raw);    // [2][3][NW * RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * NW;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = (p.Kc + KT - 1) / KT;
+  const int total = p.nterms * ktiles;
+  // per-lane, tile-invariant parts of every address (the loop below adds only wave-uniform tile offsets: the vector ALU
+  // is the co-bottleneck of this kernel -- an MFMA holds vector issue for 8 of its 16 cycles)
+  int64_t arow[2];                                   // element offset of this lane's 8 k inside row r (without lda * row: see aoff)
+  int64_t rowc[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int64_t m = m0 + wave * 32 + r * 16 + r16;
+    rowc[r] = m < p.M ? m : p.M - 1;                 // rows past the end re-read the last row; their results are never stored
+    arow[r] = 0;
+  }
+  int wsrc[WPAIRS], wdst[WPAIRS], wkk[WPAIRS];
+  bool wcol[WPAIRS];
+#pragma unroll
+  for (int h = 0; h < WPAIRS; ++h) {
+    const int idx = min(tid + h * XT, KT / 2 * NW - 1);
+    const int cc = idx % NW, kk = (idx / NW) * 2;
+    wkk[h] = kk;
+    wcol[h] = (tid + h * XT < KT / 2 * NW) && (n0 + cc < p.N);
+    wsrc[h] = kk * p.N + (n0 + cc < p.N ? n0 + cc : 0);
+    wdst[h] = cc * RS + x3_chunk(cc, kk >> 3) * 8 + (kk & 7);
+  }
+  float ra[2][8], rw[2 * WPAIRS];
+  auto load_a = [&](int ti, float (&dst)[2][8]) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;           // wave-uniform
+    const float* __restrict__ A = p.a[term] + k0 + kg * 8;
+    const int64_t lda = p.lda[term];
+    if (k0 + KT <= p.Kc) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 v = *reinterpret_cast<const float4*>(A + rowc[r] * lda + h * 4);
+          dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
+        }
+    } else {                                                         // last k tile of a term: k past Kc reads as zero
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = k0 + kg * 8 + h * 4 < p.Kc;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) v = *reinterpret_cast<const float4*>(A + rowc[r] * lda + h * 4);
+          dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
+        }
+    }
+  };
+  auto load_w = [&](int ti) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
+    const float* __restrict__ Wt = p.W + ((int64_t)term * p.Kc + k0) * p.N;
+    if (k0 + KT <= p.Kc) {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        rw[h * 2 + 0] = wcol[h] ? Wt[wsrc[h]] : 0.f;
+        rw[h * 2 + 1] = wcol[h] ? Wt[wsrc[h] + p.N] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        rw[h * 2 + 0] = (wcol[h] && k0 + wkk[h] < p.Kc) ? Wt[wsrc[h]] : 0.f;
+        rw[h * 2 + 1] = (wcol[h] && k0 + wkk[h] + 1 < p.Kc) ? Wt[wsrc[h] + p.N] : 0.f;
+      }
+    }
+  };
+  auto store_w = [&](int buf) {            // W tile transposed [column][k], split into the three planes
+    unsigned short* W0 = Wp + buf * WBUF;
+#pragma unroll
+    for (int h = 0; h < WPAIRS; ++h) {
+      if (tid + h * XT >= KT / 2 * NW) continue;
+      unsigned w1, w2, w3;
+      split3(rw[h * 2 + 0], rw[h * 2 + 1], w1, w2, w3);
+      *reinterpret_cast<unsigned*>(&W0[wdst[h]]) = w1;
+      *reinterpret_cast<unsigned*>(&W0[NW * RS + wdst[h]]) = w2;
+      *reinterpret_cast<unsigned*>(&W0[2 * NW * RS + wdst[h]]) = w3;
+    }
+  };
+  load_a(0, ra);
+  load_w(0);
+  store_w(0);
+  __syncthreads();
+  const int frag = r16 * RS + x3_chunk(r16, kg) * 8;
+  for (int ti = 0; ti < total; ++ti) {
+    float rn[2][8];
+    const bool more = ti + 1 < total;
+    if (more) { load_a(ti + 1, rn); load_w(ti + 1); }
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned pl[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(ra[r][2 * j], ra[r][2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        a[r][q] = __builtin_bit_cast(bf16x8, u32x4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+      }
+    }
+    const unsigned short* W0 = Wp + (ti & 1) * WBUF;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 w[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) w[q] = *reinterpret_cast<const bf16x8*>(&W0[q * NW * RS + (nt * 16) * RS + frag]);
+      // smallest terms first; the two row tiles alternate so that consecutive MFMAs are independent
+      f32x4 c0 = acc[0][nt], c1 = acc[1][nt];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][2], w[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][2], w[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], w[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], w[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[2], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[2], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], w[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], w[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[0], c1, 0, 0, 0);
+      acc[0][nt] = c0; acc[1][nt] = c1;
+    }
+    if (more) {
+      store_w((ti + 1) & 1);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ra[r][j] = rn[r][j];
+    }
+    __syncthreads();
+  }
+  // ---- epilogue
+  if constexpr (NT <= 4) {
+    if (p.vec_epilogue) {
+      constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
+      float* my = reinterpret_cast<float*>(lds_raw) + wave * (16 * ES);     // the loop ended with a barrier: W buffers are free
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) my[(kg * 4 + i) * ES + nt * 16 + r16] = acc[r][nt][i];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+          const int64_t m = m0 + wave * 32 + r * 16 + row;
+          const int col = n0 + seg;
+          if (m >= p.M || col >= p.N) continue;
+          float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
+          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          if (p.bias_kind && col < p.bias_cols) {
+            const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
+          if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+          *o = v;
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wave * 32 + r * 16 + kg * 4 + i;
+      if (m >= p.M) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + r16;
         if (col >= p.N) continue;
         float v = acc[r][nt][i];
         if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
@@ -1907,6 +2114,7 @@ int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "x3_form") == 0) { g_x3_form.store(value); return TGCN_OK; }
   if (key && strcmp(key, "overlap") == 0) { g_overlap.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
 }
@@ -2113,7 +2321,8 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   if (use_x3) {      // bf16x3 products on the bf16 matrix pipe
     const dim3 grid3((unsigned)((M + 255) / 256), grid.y);
 #define TGCN_PROJ3(NTV)                                                                              \
-  if (vec4) hipLaunchKernelGGL((project_x3_kernel<NTV, true>), grid3, dim3(512), 0, st, p);           \
+  if (vec4 && NTV >= 6 && g_x3_form.load() == 2) hipLaunchKernelGGL((project_x3v2_kernel<NTV>), grid3, dim3(512), 0, st, p); /* wide outputs: compute-bound */ \
+  else if (vec4) hipLaunchKernelGGL((project_x3_kernel<NTV, true>), grid3, dim3(512), 0, st, p);      \
   else hipLaunchKernelGGL((project_x3_kernel<NTV, false>), grid3, dim3(512), 0, st, p);
     switch (nts) {
       case 1: TGCN_PROJ3(1) break;
