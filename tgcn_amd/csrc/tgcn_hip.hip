@@ -377,6 +377,7 @@ std::atomic<int> g_hop_variant{0};
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
 std::atomic<int> g_overlap{0};
 std::atomic<int> g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS
+std::atomic<int> g_small_narrow{1};    // C <= 4 inputs of the one-launch path: input-side recursion (0: output-side kernel)
 std::atomic<int> g_small_dense{1};     // small dense operands on the fp32 matrix pipe (0: vector-ALU kernels only)        // layer driver: projection of pass i on a side stream under the hops of pass i+1
 
 struct SideStream { hipStream_t st = nullptr; hipEvent_t hops_done[2] = {nullptr, nullptr}; hipEvent_t proj_done[2] = {nullptr, nullptr}; };
@@ -1419,6 +1420,28 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradParams p)
 // Thread t owns vertex t (up to 1024 threads) and keeps its input row in registers (rows longer than 32 floats are
 // re-read from global memory in 32-float pieces every step: 8 loads against 512 fmaf); X W_j is VALU fmaf,
 // L . is a walk over the LDS-resident CSR reading neighbour rows of the previous buffer from LDS.
+// W'_j[c][g] = sum_k fold[k][j] W[k][c][g] (reference_power -> monomial basis), k ascending; eight loads in flight per
+// round trip instead of one (the weights come from L2: the serial form cost ~1 us per k and per step).
+__device__ __forceinline__ float folded_weight(const float* __restrict__ fold, const float* __restrict__ W, int K, int j,
+                                               int64_t stride_k, int64_t off) {
+  float w = 0.f;
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = W[(int64_t)(k + u) * stride_k + off];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w = fmaf(fold[(k + u) * K + j], v[u], w);
+  }
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = k + u < K ? W[(int64_t)(k + u) * stride_k + off] : 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (k + u < K) w = fmaf(fold[(k + u) * K + j], v[u], w);
+  return w;
+}
+
 constexpr int kSmallMaxN = 1024;  // one thread per vertex
 constexpr int kSmallCMax = 128;   // longest input row; up to 32 floats of it live in registers at a time
 inline int small_cpad(int C) { return C <= 4 ? 4 : (C <= 16 ? 16 : (C + 31) / 32 * 32); }   // rows of the LDS weight tile
@@ -1499,7 +1522,7 @@ __global__ __launch_bounds__(kSmallMaxN) void small_forward_kernel(const SmallPa
       float w = 0.f;
       if (c < C && n0 + g < p.N) {
         if (p.fold) {
-          for (int k = 0; k < p.K; ++k) w = fmaf(p.fold[k * p.K + j], p.W[((int64_t)k * C + c) * p.N + n0 + g], w);
+          w = folded_weight(p.fold, p.W, p.K, j, (int64_t)C * p.N, (int64_t)c * p.N + n0 + g);
         } else {
           w = p.W[((int64_t)j * C + c) * p.N + n0 + g];
         }
@@ -1661,6 +1684,152 @@ inline int small_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int* de
     }
   }
   return 0;
+}
+
+// ---- first layers (C <= 4 input channels, typically 1): the recursion is cheaper on the INPUT side -- the hop tensors
+// are 4 floats per vertex and stay in LDS, every step adds its term P_k W_k into NT output accumulators held in
+// registers (thread = vertex), so one workgroup covers NT = 64 / 32 / 16 output channels with ONE recursion instead of
+// one per 16-channel tile:  mode 0: P_k = L P_{k-1} (monomials, folded weight);  mode 1: T_k = 2 L T_{k-1} - T_{k-2}.
+// Fused relu + pool epilogue through wave shuffles (the `pool` vertices of a group are neighbouring lanes).
+template <int NT>
+__global__ __launch_bounds__(kSmallMaxN) void small_narrow_kernel(const SmallParams p) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int CP = 4;
+  const int n = p.n, nnz = p.nnz, C = p.C;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  const int ldn = n | 1;
+  tgcn_edge* ev = reinterpret_cast<tgcn_edge*>(smem);
+  int32_t* rowptr = reinterpret_cast<int32_t*>(smem + 2 * ((nnz + 1) / 2 * 2));
+  float* Ld = smem;
+  float* Wt = p.dense ? smem + (n * ldn + 3) / 4 * 4 : reinterpret_cast<float*>(rowptr) + (n + 1 + 3) / 4 * 4;   // CP x NT
+  const int nbuf = p.mode == 0 ? 2 : 3;
+  const int slot = tid / p.npad, i = tid % p.npad;
+  const int q = blockIdx.x * p.spw + slot, n0 = blockIdx.y * NT;
+  const bool live = q < p.q && i < n;
+  float4* Pb = reinterpret_cast<float4*>(Wt + CP * NT) + slot * (nbuf * n);     // this sample's nbuf buffers of n float4
+  if (p.dense) {
+    for (int e = tid; e < n * ldn; e += nthr) Ld[e] = 0.f;
+    __syncthreads();
+    if (tid < n)
+      for (int e = p.rowptr[tid]; e < p.rowptr[tid + 1]; ++e) Ld[tid * ldn + p.ev[e].col] += p.ev[e].val;
+  } else {
+    for (int e = tid; e < nnz; e += nthr) ev[e] = p.ev[e];
+    for (int r = tid; r <= n; r += nthr) rowptr[r] = p.rowptr[r];
+  }
+  float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* xr = p.x + ((int64_t)q * n + i) * C;
+    pk.x = xr[0];
+    if (C > 1) pk.y = xr[1];
+    if (C > 2) pk.z = xr[2];
+    if (C > 3) pk.w = xr[3];
+    Pb[i] = pk;
+  }
+  float acc[NT];
+#pragma unroll
+  for (int g = 0; g < NT; ++g) acc[g] = 0.f;
+  int cur = 1;
+  for (int k = 0; k < p.K; ++k) {
+    __syncthreads();                                   // previous step's P is complete; the weight tile is free
+    for (int e = tid; e < CP * NT; e += nthr) {        // W'_k tile (rows c >= C and columns >= N are zero)
+      const int c = e / NT, g = e % NT;
+      float w = 0.f;
+      if (c < C && n0 + g < p.N) {
+        if (p.fold) {
+          w = folded_weight(p.fold, p.W, p.K, k, (int64_t)C * p.N, (int64_t)c * p.N + n0 + g);
+        } else {
+          w = p.W[((int64_t)k * C + c) * p.N + n0 + g];
+        }
+      }
+      Wt[e] = w;
+    }
+    if (k > 0 && live) {
+      const float4* B1 = Pb + ((cur + nbuf - 1) % nbuf) * n;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.dense) {
+        for (int col = 0; col < n; ++col) {
+          const float lv = Ld[i * ldn + col];
+          const float4 y = B1[col];
+          s.x = fmaf(lv, y.x, s.x); s.y = fmaf(lv, y.y, s.y); s.z = fmaf(lv, y.z, s.z); s.w = fmaf(lv, y.w, s.w);
+        }
+      } else {
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+          const tgcn_edge ed = ev[e];
+          const float4 y = B1[ed.col];
+          s.x = fmaf(ed.val, y.x, s.x); s.y = fmaf(ed.val, y.y, s.y); s.z = fmaf(ed.val, y.z, s.z); s.w = fmaf(ed.val, y.w, s.w);
+        }
+      }
+      if (p.mode == 1 && k >= 2) {                     // one rounding, like 2*X - Xt[k-2] of the reference
+        const float4 z = Pb[((cur + nbuf - 2) % nbuf) * n + i];
+        s.x = fmaf(2.f, s.x, -z.x); s.y = fmaf(2.f, s.y, -z.y); s.z = fmaf(2.f, s.z, -z.z); s.w = fmaf(2.f, s.w, -z.w);
+      }
+      pk = s;
+      if (k + 1 < p.K) Pb[cur * n + i] = pk;
+    }
+    __syncthreads();                                   // weight tile staged (and nobody still reads the buffer written next)
+    if (live) {
+      const float pc[CP] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        if (c >= C) break;
+        const float4* wrow = reinterpret_cast<const float4*>(Wt + c * NT);
+#pragma unroll
+        for (int g4 = 0; g4 < NT / 4; ++g4) {
+          const float4 w = wrow[g4];
+          acc[g4 * 4 + 0] = fmaf(pc[c], w.x, acc[g4 * 4 + 0]);
+          acc[g4 * 4 + 1] = fmaf(pc[c], w.y, acc[g4 * 4 + 1]);
+          acc[g4 * 4 + 2] = fmaf(pc[c], w.z, acc[g4 * 4 + 2]);
+          acc[g4 * 4 + 3] = fmaf(pc[c], w.w, acc[g4 * 4 + 3]);
+        }
+      }
+    }
+    if (k > 0) cur = (cur + 1) % nbuf;
+  }
+  // ---- epilogue: bias, optional relu + max over `pool` consecutive vertices (neighbouring lanes), store
+  const float* bp = p.bias_kind == 1 ? p.bias + n0 : (p.bias_kind == 2 ? p.bias + (int64_t)(live ? i : 0) * p.N + n0 : nullptr);
+  const bool vec = (p.N & 3) == 0;
+  if (p.pool > 0) {
+    const int np = n / p.pool;
+    const bool writer = live && (i % p.pool) == 0;
+    const int64_t obase = ((int64_t)q * np + i / p.pool) * p.N + n0;
+#pragma unroll
+    for (int g = 0; g < NT; ++g) {
+      float v = acc[g] + ((bp && n0 + g < p.N) ? bp[g] : 0.f);
+      float best = v;
+      int bi = 0;
+      for (int jj = 1; jj < p.pool; ++jj) {             // lanes i+1 .. i+pool-1 of the same wave (npad and 64 are multiples of pool's group)
+        const float o = __shfl_down(v, jj, 64);
+        if (o > best || (o != o && best == best)) { best = o; bi = jj; }
+      }
+      if (p.relu) best = best > 0.f ? best : (best != best ? best : 0.f);
+      if (writer && n0 + g < p.N) {
+        p.out[obase + g] = best;
+        if (p.pool_idx) p.pool_idx[obase + g] = (uint8_t)bi;
+      }
+    }
+    return;
+  }
+  if (!live) return;
+  float* o = p.out + ((int64_t)q * n + i) * p.N + n0;
+  if (vec) {
+#pragma unroll
+    for (int g4 = 0; g4 < NT / 4; ++g4) {
+      if (n0 + g4 * 4 >= p.N) break;
+      float4 v4 = make_float4(acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]);
+      if (bp) { v4.x += bp[g4 * 4]; v4.y += bp[g4 * 4 + 1]; v4.z += bp[g4 * 4 + 2]; v4.w += bp[g4 * 4 + 3]; }
+      reinterpret_cast<float4*>(o)[g4] = v4;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < NT; ++g)
+      if (n0 + g < p.N) o[g] = acc[g] + (bp ? bp[g] : 0.f);
+  }
+}
+
+inline size_t narrow_lds_bytes(int n, int nnz, int nt, int mode, int dense, int spw = 1) {
+  const size_t graph = dense ? (size_t)((n * (n | 1) + 3) / 4 * 4)
+                             : 2 * (size_t)((nnz + 1) / 2 * 2) + (size_t)((n + 1 + 3) / 4 * 4);
+  return (graph + (size_t)4 * nt + (size_t)spw * (mode == 0 ? 2 : 3) * n * 4) * sizeof(float);
 }
 
 // ---- the basis of the layer for small graphs, for the weight gradient: terms k = 1 .. K-1 of
@@ -1855,7 +2024,7 @@ __global__ __launch_bounds__(NW * 64) void small_dense_kernel(const SmallParams 
       float w = 0.f;
       if (c < C && n0 + g < p.N) {
         if (p.fold) {
-          for (int k = 0; k < p.K; ++k) w = fmaf(p.fold[k * p.K + j], p.W[((int64_t)k * C + c) * p.N + n0 + g], w);
+          w = folded_weight(p.fold, p.W, p.K, j, (int64_t)C * p.N, (int64_t)c * p.N + n0 + g);
         } else {
           w = p.W[((int64_t)j * C + c) * p.N + n0 + g];
         }
@@ -2114,6 +2283,7 @@ int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "small_narrow") == 0) { g_small_narrow.store(value); return TGCN_OK; }
   if (key && strcmp(key, "x3_form") == 0) { g_x3_form.store(value); return TGCN_OK; }
   if (key && strcmp(key, "overlap") == 0) { g_overlap.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
@@ -2478,6 +2648,34 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
   if (!ntc) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: n=%lld nnz=%lld C=%d does not fit in LDS", (long long)A->n, (long long)A->nnz, C);
   if ((N + ntc - 1) / ntc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_small: grid too large");
   p.dense = dense;
+  if (C <= 4 && g_small_narrow.load() && (pool == 0 || (pool <= 64 && (64 % pool) == 0))) {
+    // first layers: recursion on the 4-float input side, all of NT output channels per workgroup (small_narrow_kernel)
+    p.npad = (p.n + 63) / 64 * 64;
+    int nt = N > 32 ? 64 : (N > 16 ? 32 : 16);
+    while (nt > 16 && q * ((N + nt - 1) / nt) < 256) nt /= 2;            // fill the chip before widening the tile
+    int spw = 1;
+    const int64_t tiles = (N + nt - 1) / nt;
+    while ((spw + 1) * p.npad <= kSmallMaxN && narrow_lds_bytes(p.n, p.nnz, nt, mode, dense, spw + 1) <= 160 * 1024 &&
+           (q + spw) / (spw + 1) * tiles >= 512)
+      ++spw;
+    if (narrow_lds_bytes(p.n, p.nnz, nt, mode, dense, spw) <= 160 * 1024) {
+      p.spw = spw;
+      const size_t lds = narrow_lds_bytes(p.n, p.nnz, nt, mode, dense, spw);
+      const dim3 grid((unsigned)((q + spw - 1) / spw), (unsigned)tiles);
+      hipStream_t st = (hipStream_t)stream;
+      const unsigned nthreads = (unsigned)(p.npad * spw);
+      ProfScope ps(TGCN_PROF_SMALL, st);
+#define TGCN_NARROW(NTV)                                                                     \
+  {                                                                                          \
+    allow_large_lds((const void*)small_narrow_kernel<NTV>, 160 * 1024);                      \
+    hipLaunchKernelGGL((small_narrow_kernel<NTV>), grid, dim3(nthreads), lds, st, p);        \
+  }
+      if (nt == 64) TGCN_NARROW(64) else if (nt == 32) TGCN_NARROW(32) else TGCN_NARROW(16)
+#undef TGCN_NARROW
+      TGCN_CHECK_LAUNCH("tgcn_cheb_forward_small_f32 (narrow input)");
+      return TGCN_OK;
+    }
+  }
   // samples per workgroup: as many as fit the 1024-thread / 160 KB budget, but keep >= 512 workgroups in the grid
   p.npad = (p.n + 63) / 64 * 64;
   int spw = 1;
