@@ -30,14 +30,16 @@ def main():
     a = ap.parse_args()
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
-    ks = sorted(glob.glob(os.path.join(a.src, "prof_kt", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+    ks = sorted(glob.glob(os.path.join(a.src, "prof_kt", "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(a.src, "prof_kt", "*_kernel_stats.csv")),
+                key=os.path.getmtime, reverse=True)
     if ks:
         rows = list(csv.reader(open(ks[0])))
         keep = [rows[0]] + [r for r in rows[1:] if short(r[0]) or float(r[4]) >= 0.5]
         csv.writer(open(os.path.join(prof, a.tag + "_kernel_stats.csv"), "w")).writerows(keep)
     res = {}
     for d in ("prof_fetch", "prof_write", "prof_tcc"):
-        for f in sorted(glob.glob(os.path.join(a.src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
+        for f in sorted(glob.glob(os.path.join(a.src, d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(a.src, d, "*_counter_collection.csv")),
+                        key=os.path.getmtime)[-1:]:
             acc = collections.defaultdict(lambda: collections.defaultdict(list))
             for row in csv.DictReader(open(f)):
                 k = short(row["Kernel_Name"])
