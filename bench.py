@@ -56,7 +56,7 @@ def build_workload(name, labeling, device, n_override=None, nnz_override=None):
         row = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1]).to(device)
         col, val = torch.as_tensor(z["col"]).long().to(device), torch.as_tensor(z["val"]).to(device)
         spec = dict(cls="TGCNCheb_H", q=512, H=15, f=1, g=32, K=10, desc="HCP aparc DTI graph n=148 nnz=%d (dense), TGCNCheb_H(L,1,32,10,15), q=512" % col.numel())
-    elif name in ("cfg3", "cfg2"):
+    elif name in ("cfg3", "cfg2", "cfg2w"):
         z = np.load(os.path.join(ROOT, "tests", "golden", "GCNCheb_grid784_q3_f1_g8_K5_x2d.npz"))
         n = int(z["n"])
         rowptr = torch.as_tensor(z["rowptr"])
@@ -64,6 +64,8 @@ def build_workload(name, labeling, device, n_override=None, nnz_override=None):
         col, val = torch.as_tensor(z["col"]).long().to(device), torch.as_tensor(z["val"]).to(device)
         if name == "cfg3":
             spec = dict(cls="TGCNCheb_H", q=64, H=28, f=1, g=64, K=5, desc="MNIST 8-NN grid n=784 nnz=6396, TGCNCheb_H(L,1,64,5,28), q=64")
+        elif name == "cfg2w":   # the f = 64 variant of cfg2 (a second layer)
+            spec = dict(cls="GCNCheb", q=128, H=1, f=64, g=64, K=5, desc="MNIST 8-NN grid n=784 nnz=6396, GCNCheb(L,64,64,5), q=128")
         else:
             spec = dict(cls="GCNCheb", q=128, H=1, f=1, g=64, K=5, desc="MNIST 8-NN grid n=784 nnz=6396, GCNCheb(L,1,64,5), q=128")
     else:

@@ -58,6 +58,26 @@ def test_schedule_covers_every_entry_once(lpr):
     assert np.all(np.diff(first_col) >= 0)
 
 
+def test_dense_copy_of_small_dense_operands():
+    """Operands with n <= 256 that store >= 1/4 of their entries carry a dense copy (duplicates summed) for the
+    matrix-pipe kernels; sparse or larger ones do not."""
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(5)
+    n = 40
+    row, col = rng.integers(0, n, 900), rng.integers(0, n, 900)            # with duplicates
+    val = rng.standard_normal(900).astype(np.float32)
+    op = GraphOperand.from_coo(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val))
+    assert op.dense is not None and op.struct.dense == op.dense.data_ptr()
+    ref = np.zeros((n, n), np.float64)
+    np.add.at(ref, (row, col), val.astype(np.float64))
+    assert np.abs(op.dense.numpy() - ref).max() <= 1e-5
+    sparse = GraphOperand.from_coo(n, torch.as_tensor(row[:100]), torch.as_tensor(col[:100]), torch.as_tensor(val[:100]))
+    assert sparse.dense is None and not sparse.struct.dense
+    big = GraphOperand.from_coo(300, torch.as_tensor(rng.integers(0, 300, 40000)), torch.as_tensor(rng.integers(0, 300, 40000)),
+                                torch.as_tensor(rng.standard_normal(40000).astype(np.float32)))
+    assert big.dense is None
+
+
 def test_operand_constructors_agree():
     from tgcn_amd.graph import GraphOperand
     import scipy.sparse as sp
