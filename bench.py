@@ -199,12 +199,18 @@ def main():
             torch.cuda.synchronize()
 
     with torch.no_grad():
+        # set-up, not a step: one forward so that the caching allocator owns the output / workspace blocks (a cold
+        # hipMalloc of the 41 GB cfg5 output takes ~1 s); `out = None` first keeps it at ONE output buffer, otherwise the
+        # second forward would allocate its result while the first is still referenced
+        out = layer(x)
         for _ in range(args.warmup):
+            out = None
             out = layer(x)
         sync_all()
         _lib.profile_start(65536)
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            out = None
             out = layer(x)
         sync_all()
         dt = time.perf_counter() - t0

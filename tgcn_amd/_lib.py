@@ -7,7 +7,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libtgcn_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", "tgcn_hip.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", "tgcn_hip.hip")]      # one translation unit; the kernels are in csrc/*.h
+HEADERS = [os.path.join(_HERE, "csrc", h) for h in ("common.h", "hop.h", "project.h", "wgrad.h", "small_graph.h", "pool_relayout.h")]
 INCLUDE = os.path.join(ROOT, "include")
 
 
@@ -87,7 +88,7 @@ def build(verbose=False):
     """Compile the HIP sources for gfx950 into tgcn_amd/lib/libtgcn_hip.so (hipcc cross-compiles without a GPU)."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s)
-                                        for s in SOURCES + [os.path.join(INCLUDE, "tgcn_hip.h")]):
+                                        for s in SOURCES + HEADERS + [os.path.join(INCLUDE, "tgcn_hip.h")]):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-I", INCLUDE, "-o", LIB_PATH] + SOURCES

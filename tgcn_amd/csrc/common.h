@@ -1,0 +1,89 @@
+// common.h -- error reporting, launch timing, tuning switches and small host helpers shared by every section
+// Part of the single translation unit tgcn_hip.hip (included once, inside its anonymous namespace).
+#pragma once
+
+
+thread_local char g_err[512] = "";
+
+#define TGCN_FAIL(code, ...)                    \
+  do {                                          \
+    snprintf(g_err, sizeof(g_err), __VA_ARGS__); \
+    return (code);                              \
+  } while (0)
+
+#define TGCN_CHECK_LAUNCH(what)                                                         \
+  do {                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                  \
+    if (e_ != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr int kBlock = 256;
+
+// ---- optional launch timing (bench / tests): hipEvent pairs recorded around launches on their own stream
+struct ProfRec { hipEvent_t a, b; int kind; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+std::atomic<int> g_prof_cap{0};
+
+struct ProfScope {
+  hipEvent_t b = nullptr;
+  hipStream_t st;
+  ProfScope(int kind, hipStream_t s) : st(s) {
+    if (g_prof_cap.load(std::memory_order_relaxed) <= 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if ((int)g_prof.size() >= g_prof_cap.load()) return;
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    r.kind = kind;
+    (void)hipEventRecord(r.a, st);
+    b = r.b;
+    g_prof.push_back(r);
+  }
+  ~ProfScope() { if (b) (void)hipEventRecord(b, st); }
+};
+
+// Kernels that take more than 64 KB of dynamic LDS.  The attribute belongs to the calling thread's current device
+// (nn.DataParallel drives several devices from one process), so it is set once per (device, kernel).
+inline void allow_large_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert(std::make_pair(dev, fn)).second)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);   // a refusal surfaces as a launch error
+}
+
+std::atomic<int> g_hop_variant{0};
+std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
+std::atomic<int> g_overlap{0};
+std::atomic<int> g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS
+std::atomic<int> g_small_narrow{1};    // C <= 4 inputs of the one-launch path: input-side recursion (0: output-side kernel)
+std::atomic<int> g_small_dense{1};     // small dense operands on the fp32 matrix pipe (0: vector-ALU kernels only)        // layer driver: projection of pass i on a side stream under the hops of pass i+1
+
+struct SideStream { hipStream_t st = nullptr; hipEvent_t hops_done[2] = {nullptr, nullptr}; hipEvent_t proj_done[2] = {nullptr, nullptr}; };
+std::mutex g_side_mu;
+SideStream g_side[16];
+
+// One helper stream + 4 events per device, created on first use and kept for the life of the process.
+SideStream* side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream& s = g_side[dev];
+  if (!s.st) {
+    if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { s.st = nullptr; return nullptr; }
+    for (int i = 0; i < 2; ++i) {
+      if (hipEventCreateWithFlags(&s.hops_done[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&s.proj_done[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(s.st);
+        s.st = nullptr;
+        return nullptr;
+      }
+    }
+  }
+  return &s;
+}
+
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,380 @@
+// hop.h -- S = L X, Y = alpha S + beta Z (+ gamma Z2): hop_kernel, hop_fixup_kernel, their geometry and launch helpers
+// Part of the single translation unit tgcn_hip.hip (included once, inside its anonymous namespace).
+#pragma once
+
+// --------------------------------------------------------------------------------------------------
+// hop
+// --------------------------------------------------------------------------------------------------
+struct HopParams {
+  const int32_t* rowptr;
+  const tgcn_edge* ev;
+  const int32_t* blk_row;
+  const int32_t* seg_row;
+  const int32_t* seg_e0;
+  const int32_t* seg_e1;
+  const int32_t* seg_slot;
+  const int32_t* long_row;
+  const int32_t* long_slot;
+  const float* X;
+  const float* Z;
+  const float* Z2;
+  float* Y;
+  float* P;
+  float* partial;
+  int64_t x_bs, x_ld, z_bs, z_ld, z2_bs, z2_ld, y_bs, y_ld, p_bs, p_ld;
+  float alpha, beta, gamma;
+  int32_t nblk, nseg, nlong, nhuge, row_thresh;
+  int32_t C, nb, nchunks, cpad;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = __builtin_nontemporal_load(p);
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// XCD-aware block id: blocks b and b+8 share an XCD (observed round-robin dispatch), so hand each XCD a
+// contiguous range of row blocks -- neighbouring rows share neighbour columns in its private L2.
+// Bijective for every nblk (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// Tuning bits of the hop kernel (NTM): which accesses carry the non-temporal hint, and ev prefetch.
+constexpr int kNtEdges = 1, kNtStores = 2;
+
+template <int VEC>
+__device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    __builtin_nontemporal_store(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(p));
+  } else {
+    __builtin_nontemporal_store(v[0], p);
+  }
+}
+
+template <int NTM>
+__device__ __forceinline__ void load_edge(const tgcn_edge* __restrict__ ev, int e, int& c, float& v) {
+  if constexpr (NTM & kNtEdges) {
+    using i2 = __attribute__((ext_vector_type(2))) int;
+    const i2 t = __builtin_nontemporal_load(reinterpret_cast<const i2*>(ev + e));
+    c = t.x;
+    v = __int_as_float(t.y);
+  } else {
+    const tgcn_edge t = ev[e];
+    c = t.col;
+    v = t.val;
+  }
+}
+
+template <int VEC, int NTM>
+__device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int c0, const float (&s)[VEC]) {
+  if (p.P) {
+    if constexpr (NTM & kNtStores) store_vec_nt<VEC>(p.P + (int64_t)b * p.p_bs + (int64_t)r * p.p_ld + c0, s);
+    else store_vec<VEC>(p.P + (int64_t)b * p.p_bs + (int64_t)r * p.p_ld + c0, s);
+  }
+  float y[VEC];
+  if (p.Z) {
+    float z[VEC];
+    load_vec_nt<VEC>(p.Z + (int64_t)b * p.z_bs + (int64_t)r * p.z_ld + c0, z);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = fmaf(p.alpha, s[i], p.beta * z[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = p.alpha * s[i];
+  }
+  if (p.Z2) {   // second addend (Clenshaw step of the project-first path): y += gamma * z2
+    float z2[VEC];
+    load_vec_nt<VEC>(p.Z2 + (int64_t)b * p.z2_bs + (int64_t)r * p.z2_ld + c0, z2);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = fmaf(p.gamma, z2[i], y[i]);
+  }
+  if (p.Y) {
+    if constexpr (NTM & kNtStores) store_vec_nt<VEC>(p.Y + (int64_t)b * p.y_bs + (int64_t)r * p.y_ld + c0, y);
+    else store_vec<VEC>(p.Y + (int64_t)b * p.y_bs + (int64_t)r * p.y_ld + c0, y);
+  }
+}
+
+// Sum of val_e * X[col_e, c0..c0+VEC) over stored entries [e0[rr], e1[rr]) of R rows (or segments) at once, by one
+// group of LPR lanes.  Per row the group reads LPR entries with one coalesced 8-byte load per lane and hands them
+// round with in-register shuffles; gathers are issued U at a time per row, so R*U 16-byte loads are in flight per
+// lane.  R > 1 keeps R independent rowptr -> entry -> gather chains going, which is what low-degree rows on wide
+// operands need (measured on the mesh config); entries are summed in stored order: deterministic.
+template <int LPR, int VEC, int UU, int R, int NTM>
+__device__ __forceinline__ void accum_multi(const tgcn_edge* __restrict__ ev, const int (&e0)[R], const int (&e1)[R], int t,
+                                            const float* __restrict__ Xc, int64_t ldx, float (&acc)[R][VEC]) {
+  constexpr int U = LPR < UU ? LPR : UU;
+  int len_max = 0;
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) len_max = max(len_max, e1[rr] - e0[rr]);
+  for (int off = 0; off < len_max; off += LPR) {
+    int my_c[R], cnt[R];
+    float my_v[R];
+    int cmax = 0;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      my_c[rr] = 0;
+      my_v[rr] = 0.f;
+      const int e = e0[rr] + off + t;
+      if (e < e1[rr]) load_edge<NTM>(ev, e, my_c[rr], my_v[rr]);
+      cnt[rr] = min(LPR, max(0, e1[rr] - e0[rr] - off));
+      cmax = max(cmax, cnt[rr]);
+    }
+    for (int j0 = 0; j0 < LPR; j0 += U) {
+      if (j0 >= cmax) break;
+      float xv[R][U][VEC];
+      float vv[R][U];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = __shfl(my_c[rr], j0 + u, LPR);
+          vv[rr][u] = __shfl(my_v[rr], j0 + u, LPR);   // 0 past the end of the row
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) xv[rr][u][i] = 0.f;
+          if (j0 + u < cnt[rr]) load_vec<VEC>(Xc + (int64_t)c * ldx, xv[rr][u]);
+        }
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[rr][i] = fmaf(vv[rr][u], xv[rr][u][i], acc[rr][i]);
+    }
+  }
+}
+
+template <int LPR, int VEC, int UU, int R, int NTM>
+__global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
+  constexpr int GPB = kBlock / LPR;
+  const int tid = threadIdx.x;
+  const int t = tid % LPR;
+  const int gib = tid / LPR;
+  const int chunk = blockIdx.y % p.nchunks;
+  const int b = blockIdx.y / p.nchunks;
+  const int c0 = (chunk * LPR + t) * VEC;
+  const bool cact = c0 < p.C;
+  const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
+  int bid = blockIdx.x;
+  if (bid < p.nblk) {
+    bid = xcd_remap(bid, p.nblk);
+    const int r0 = p.blk_row[bid], r1 = p.blk_row[bid + 1];
+    for (int rb = r0 + gib; rb < r1; rb += GPB * R) {
+      int e0[R], e1[R];
+      bool live[R];
+      float acc[R][VEC];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const int r = rb + rr * GPB;
+        e0[rr] = e1[rr] = 0;
+        if (r < r1) { e0[rr] = p.rowptr[r]; e1[rr] = p.rowptr[r + 1]; }
+        live[rr] = (r < r1) && (e1[rr] - e0[rr] <= p.row_thresh);
+        if (!live[rr]) e1[rr] = e0[rr];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[rr][i] = 0.f;
+      }
+      accum_multi<LPR, VEC, UU, R, NTM>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+        if (live[rr] && cact) finish_row<VEC, NTM>(p, b, rb + rr * GPB, c0, acc[rr]);
+    }
+  } else {
+    const int sb = (bid - p.nblk) * GPB * R + gib;
+    int e0[R], e1[R];
+    float acc[R][VEC];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const int s = sb + rr * GPB;
+      e0[rr] = e1[rr] = 0;
+      if (s < p.nseg) { e0[rr] = p.seg_e0[s]; e1[rr] = p.seg_e1[s]; }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[rr][i] = 0.f;
+    }
+    accum_multi<LPR, VEC, UU, R, NTM>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const int s = sb + rr * GPB;
+      if (s >= p.nseg) continue;
+      const int slot = p.seg_slot[s];
+      if (slot < 0) {
+        if (cact) finish_row<VEC, NTM>(p, b, p.seg_row[s], c0, acc[rr]);
+      } else {
+        store_vec<VEC>(p.partial + ((int64_t)slot * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc[rr]);
+      }
+    }
+  }
+}
+
+// Folds the partial sums of rows that were cut into several segments, in slot order (deterministic).
+// Blocks [0, nhuge): one row each, the block's groups sum interleaved slots and combine through LDS in group
+// order; the remaining blocks: one row per lane group.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(kBlock) void hop_fixup_kernel(const HopParams p) {
+  constexpr int GPB = kBlock / LPR;
+  constexpr int UF = 4;
+  __shared__ float red[GPB * LPR * VEC];
+  const int tid = threadIdx.x;
+  const int t = tid % LPR;
+  const int gib = tid / LPR;
+  const int chunk = blockIdx.y % p.nchunks;
+  const int b = blockIdx.y / p.nchunks;
+  const int c0 = (chunk * LPR + t) * VEC;
+  const bool huge = (int)blockIdx.x < p.nhuge;
+  const int i = huge ? (int)blockIdx.x : p.nhuge + ((int)blockIdx.x - p.nhuge) * GPB + gib;
+  const bool valid = i < p.nlong;
+  const int row = valid ? p.long_row[i] : 0;
+  const int s0 = valid ? p.long_slot[i] : 0, s1 = valid ? p.long_slot[i + 1] : 0;
+  const int first = huge ? s0 + gib : s0, step = huge ? GPB : 1;
+  const float* base = p.partial + (int64_t)b * p.cpad + c0;
+  const int64_t sstride = (int64_t)p.nb * p.cpad;
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  int s = first;
+  for (; s + (UF - 1) * step < s1; s += UF * step) {
+    float v[UF][VEC];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) load_vec_nt<VEC>(base + (int64_t)(s + u * step) * sstride, v[u]);
+#pragma unroll
+    for (int u = 0; u < UF; ++u)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += v[u][k];
+  }
+  for (; s < s1; s += step) {
+    float v[VEC];
+    load_vec_nt<VEC>(base + (int64_t)s * sstride, v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+  }
+  if (huge) {  // block-uniform branch
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[(gib * LPR + t) * VEC + k] = acc[k];
+    __syncthreads();
+    if (gib != 0) return;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int g = 0; g < GPB; ++g)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += red[(g * LPR + t) * VEC + k];
+  }
+  if (valid && c0 < p.C) finish_row<VEC, 0>(p, b, row, c0, acc);
+}
+
+struct HopGeom {
+  int vec, lpr, nchunks, cpad;
+};
+
+inline HopGeom hop_geom(int32_t C, int aligned16) {
+  HopGeom g;
+  g.vec = (aligned16 && (C % 4 == 0)) ? 4 : 1;
+  const int lanes = (C + g.vec - 1) / g.vec;
+  int lpr = 1;
+  while (lpr < lanes && lpr < 64) lpr <<= 1;
+  g.lpr = lpr;
+  g.nchunks = (lanes + lpr - 1) / lpr;
+  g.cpad = g.nchunks * lpr * g.vec;
+  return g;
+}
+
+template <int LPR, int VEC, int U, int R>
+inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
+  constexpr int GPB = kBlock / LPR;
+  grid.x = (unsigned)(p.nblk + (p.nseg + GPB * R - 1) / (GPB * R));
+  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, 0>), grid, dim3(kBlock), 0, st, p);
+}
+
+// developer variants of the two float4 shapes that matter for the benchmarks (tools/hop_bench.py)
+inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3 grid) {
+  const int v = g_hop_variant.load();
+  if (lpr == 16) {
+    switch (v) {
+      case 1: launch_hop<16, 4, 8, 1>(st, p, grid); return true;
+      case 2: launch_hop<16, 4, 4, 2>(st, p, grid); return true;
+      case 3: launch_hop<16, 4, 2, 1>(st, p, grid); return true;
+      default: return false;
+    }
+  }
+  if (lpr == 4) {
+    switch (v) {
+      case 1: launch_hop<4, 4, 8, 1>(st, p, grid); return true;
+      case 2: launch_hop<4, 4, 4, 2>(st, p, grid); return true;
+      case 3: launch_hop<4, 4, 4, 4>(st, p, grid); return true;
+      case 4: launch_hop<4, 4, 2, 4>(st, p, grid); return true;
+      default: return false;
+    }
+  }
+  if (lpr == 64) {
+    switch (v) {
+      case 1: launch_hop<64, 4, 4, 1>(st, p, grid); return true;
+      case 2: launch_hop<64, 4, 4, 2>(st, p, grid); return true;
+      case 3: launch_hop<64, 4, 8, 2>(st, p, grid); return true;
+      case 4: launch_hop<64, 4, 8, 1>(st, p, grid); return true;
+      default: return false;
+    }
+  }
+  return false;
+}
+
+// rows interleaved per lane group: wide operands (a whole wave per row chunk) run 4 rows at once
+template <int L> struct HopRows { static constexpr int value = (L == 64) ? 4 : 1; };
+
+template <int VEC>
+int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
+#define TGCN_HOP_CASE(L)                                                                    \
+  case L: {                                                                                 \
+    { ProfScope ps(TGCN_PROF_HOP, st);                                                      \
+      if (!(VEC == 4 && g_hop_variant.load() != 0 && launch_hop_variant(L, st, p, grid))) { \
+        /* interleave rows only when the grid still fills the chip afterwards */            \
+        if (HopRows<L>::value > 1 && (int64_t)p.nblk * grid.y >= 4096)                       \
+          launch_hop<L, VEC, 4, HopRows<L>::value>(st, p, grid);                            \
+        else launch_hop<L, VEC, 4, 1>(st, p, grid);                                         \
+      } }                                                                                   \
+    if (p.nlong > 0) { ProfScope ps(TGCN_PROF_HOP_FIXUP, st);                               \
+      hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); }   \
+  } break;
+  switch (lpr) {
+    TGCN_HOP_CASE(1)
+    TGCN_HOP_CASE(2)
+    TGCN_HOP_CASE(4)
+    TGCN_HOP_CASE(8)
+    TGCN_HOP_CASE(16)
+    TGCN_HOP_CASE(32)
+    TGCN_HOP_CASE(64)
+    default:
+      TGCN_FAIL(TGCN_ERR_INVALID, "hop: bad lanes_per_row %d", lpr);
+  }
+#undef TGCN_HOP_CASE
+  TGCN_CHECK_LAUNCH("tgcn_csr_hop_f32");
+  return TGCN_OK;
+}
+
+inline bool aligned4(const tgcn_dense* d) {
+  return d == nullptr || d->ptr == nullptr ||
+         (((uintptr_t)d->ptr & 15) == 0 && (d->batch_stride & 3) == 0 && (d->row_stride & 3) == 0);
+}

@@ -1,0 +1,97 @@
+// pool_relayout.h -- (Q,n,C) -> (n,Q,C) re-layout, gcn_pool / gcn_pool_4 and the fused relu + pool epilogue pass
+// Part of the single translation unit tgcn_hip.hip (included once, inside its anonymous namespace).
+#pragma once
+
+// --------------------------------------------------------------------------------------------------
+// relayout (Q,n,C) -> (n,Q,C), C <= 32
+// --------------------------------------------------------------------------------------------------
+constexpr int kRelT = 16;
+__global__ __launch_bounds__(kBlock) void relayout_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int64_t Q, int64_t n, int C) {
+  __shared__ float tile[kRelT * kRelT * 32];
+  const int64_t i0 = (int64_t)blockIdx.x * kRelT, q0 = (int64_t)blockIdx.y * kRelT;
+  const int seg = kRelT * C;  // floats per (q, 16 vertices) or per (vertex, 16 q)
+  for (int e = threadIdx.x; e < kRelT * seg; e += kBlock) {
+    const int q = e / seg, rem = e % seg;
+    float v = 0.f;
+    if (q0 + q < Q && i0 + rem / C < n) v = in[((q0 + q) * n + i0) * C + rem];
+    tile[e] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kRelT * seg; e += kBlock) {
+    const int i = e / seg, rem = e % seg;
+    const int q = rem / C, c = rem % C;
+    if (i0 + i < n && q0 + q < Q) out[((i0 + i) * Q + q0) * C + rem] = tile[(q * kRelT + i) * C + c];
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// pooling
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void relu_pool_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           uint8_t* __restrict__ idx, int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;
+    const int c = (int)(o % f);
+    const float* src = x + row * p * f + c;
+    float best = src[0];
+    int bi = 0;
+    for (int j = 1; j < p; ++j) {
+      const float v = src[(int64_t)j * f];
+      if (v > best || (v != v && best == best)) { best = v; bi = j; }
+    }
+    out[o] = best > 0.f ? best : (best != best ? best : 0.f);
+    if (idx) idx[o] = (uint8_t)bi;
+  }
+}
+
+// grad wrt the layer output of max-pool(relu(.)): the pooled gradient goes to the arg-max vertex where z > 0
+__global__ __launch_bounds__(kBlock) void relu_pool_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ z,
+                                                               const uint8_t* __restrict__ idx, float* __restrict__ gy,
+                                                               int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;
+    const int c = (int)(o % f);
+    const int bi = idx[o];
+    const float g = z[o] > 0.f ? gz[o] : 0.f;
+    float* dst = gy + row * p * f + c;
+    for (int j = 0; j < p; ++j) dst[(int64_t)j * f] = (j == bi) ? g : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pool_max_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int32_t* __restrict__ idx, int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;  // (q, i_out) flattened
+    const int c = (int)(o % f);
+    const float* src = x + row * p * f + c;
+    float best = src[0];
+    int bi = 0;
+    for (int j = 1; j < p; ++j) {
+      const float v = src[(int64_t)j * f];
+      if (v > best || (v != v && best == best)) {  // NaN propagates like torch.max
+        best = v;
+        bi = j;
+      }
+    }
+    out[o] = best;
+    if (idx) idx[o] = bi;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pool_max_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx,
+                                                              float* __restrict__ gi, int64_t total, int f, int p) {
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = o / f;
+    const int c = (int)(o % f);
+    const int bi = idx[o];
+    const float g = go[o];
+    float* dst = gi + row * p * f + c;
+    for (int j = 0; j < p; ++j) dst[(int64_t)j * f] = (j == bi) ? g : 0.f;
+  }
+}
+
+inline int grid_1d(int64_t total) {
+  int64_t g = (total + kBlock - 1) / kBlock;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}

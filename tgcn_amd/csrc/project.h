@@ -1,0 +1,829 @@
+// project.h -- out = sum_t A_t W_t + bias: exact-fp32 MFMA kernels, bf16x3 kernels, the vector-ALU kernel for narrow contractions
+// Part of the single translation unit tgcn_hip.hip (included once, inside its anonymous namespace).
+#pragma once
+
+// --------------------------------------------------------------------------------------------------
+// projection (fp32 MFMA)
+// --------------------------------------------------------------------------------------------------
+constexpr int kMaxTerms = 32;
+
+struct ProjParams {
+  const float* a[kMaxTerms];
+  int64_t lda[kMaxTerms];
+  const float* W;
+  const float* bias;
+  float* out;
+  int64_t M, ldo, n_vertices, interleave;
+  int32_t Kc, N, nterms, bias_kind, accumulate, vec_epilogue;
+  int32_t bias_ld, bias_cols;   // bias row length and number of leading output columns that receive it
+  int32_t win_n, win_t;   // > 0: row m of A_t is the window starting at A_t[(m / win_n) * win_t + (m % win_n)]
+};
+
+// float offset of row m of a term: plain row stride, or overlapping time windows of a (vertex, T) series
+__device__ __forceinline__ int64_t proj_row_off(const ProjParams& p, int64_t m, int64_t lda) {
+  return p.win_n > 0 ? (m / p.win_n) * p.win_t + (m % p.win_n) : m * lda;
+}
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Streaming-W kernel: block = 4 waves, 128 output rows; wave w owns rows [32w,32w+32) x NT*16 columns as 2*NT accumulators of
+// v_mfma_f32_16x16x4_f32 (A[l&15][k=l>>4], B[k=l>>4][l&15], D col=l&15,row=(l>>4)*4+reg).
+// LDS strides: As 34 (== 2 mod 32) and Ws == 16 mod 32 make both fragment reads conflict-free.
+template <int NT, bool VEC4>
+__global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
+  constexpr int BM = 128, KT = 32, AS = KT + 2;   // 4 waves x 32 rows; wave = two 16-row MFMA tiles sharing B fragments
+  constexpr int NW = NT * 16;
+  constexpr int NS = (NW % 32 == 0) ? NW + 16 : NW;
+  constexpr int WREG = (KT * NW) / kBlock;
+  __shared__ float As[BM * AS];
+  __shared__ float Ws[KT * NS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * NW;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = (p.Kc + KT - 1) / KT;
+  const int total = p.nterms * ktiles;
+
+  // software pipeline: tile t+1 travels global -> registers while tile t is multiplied out of LDS
+  float ra[16], rw[WREG];
+  auto load_tile = [&](int ti) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
+    const float* __restrict__ A = p.a[term];
+    const int64_t lda = p.lda[term];
+    const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
+        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+        ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 16; ++h) {
+        const int row = (tid >> 5) + h * 8, kk = tid & 31;
+        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        const float v = A[proj_row_off(p, rr, lda) + kc];
+        ra[h] = ok ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < WREG; ++h) {
+      const int idx = tid + h * kBlock;
+      const int kk = idx / NW, cc = idx % NW;
+      const bool ok = (k0 + kk < p.Kc) && (n0 + cc < p.N);
+      const float v = Wt[(int64_t)(ok ? k0 + kk : 0) * p.N + (ok ? n0 + cc : 0)];
+      rw[h] = ok ? v : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 32, kk = (tid & 7) * 4;
+        float2* d = reinterpret_cast<float2*>(&As[row * AS + kk]);
+        d[0] = make_float2(ra[h * 4 + 0], ra[h * 4 + 1]);
+        d[1] = make_float2(ra[h * 4 + 2], ra[h * 4 + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 16; ++h) As[((tid >> 5) + h * 8) * AS + (tid & 31)] = ra[h];
+    }
+#pragma unroll
+    for (int h = 0; h < WREG; ++h) {
+      const int idx = tid + h * kBlock;
+      Ws[(idx / NW) * NS + (idx % NW)] = rw[h];
+    }
+  };
+
+  load_tile(0);
+  const float* arow = &As[(wave * 32 + (lane & 15)) * AS + (lane >> 4)];
+  const float* brow = &Ws[(lane >> 4) * NS + (lane & 15)];
+  for (int ti = 0; ti < total; ++ti) {
+    __syncthreads();   // everyone is done reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (ti + 1 < total) load_tile(ti + 1);
+#pragma unroll
+    for (int ks = 0; ks < KT / 4; ++ks) {   // K tail: the staged tile is zero-padded
+      const float a0 = arow[ks * 4];
+      const float a1 = arow[16 * AS + ks * 4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = brow[ks * 4 * NS + nt * 16];
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: bias, row map, store
+  const int col_l = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wave * 32 + r * 16 + (lane >> 4) * 4 + i;
+      if (m >= p.M) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + col_l;
+        if (col >= p.N) continue;
+        float v = acc[r][nt][i];
+        if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+        else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+        float* o = p.out + orow * p.ldo + col;
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
+// ---- bf16x3 variant of the streaming-W kernel: fp32-accurate products on the bf16 matrix pipe (16x the fp32 MFMA
+// rate).  Every fp32 operand is split into three bf16 terms a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1),
+// a3 = bf16(a - a1 - a2): 24 mantissa bits in all, the subtractions are exact) and the product is summed as
+// a3w1 + a2w2 + a1w3 + a2w1 + a1w2 + a1w1 with v_mfma_f32_16x16x32_bf16 in fp32 accumulators; the three dropped
+// cross terms are below 2^-24 of |a w|.  6 bf16 MFMAs replace 8 fp32 ones per 32 k at 1/2 the cycles each.
+// Operand maps (gfx950): A[row = l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4) + j][col = l&15], j = 0..7; C/D as fp32.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ void split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const bf16x2 h = {(__bf16)a, (__bf16)b};                    // v_cvt_pk_bf16_f32, round to nearest even
+  const unsigned hu = __builtin_bit_cast(unsigned, h);
+  const float ra = a - __uint_as_float(hu << 16), rb = b - __uint_as_float(hu & 0xFFFF0000u);
+  const bf16x2 m = {(__bf16)ra, (__bf16)rb};
+  const unsigned mu = __builtin_bit_cast(unsigned, m);
+  const float sa = ra - __uint_as_float(mu << 16), sb = rb - __uint_as_float(mu & 0xFFFF0000u);
+  const bf16x2 l = {(__bf16)sa, (__bf16)sb};
+  p1 = hu; p2 = mu; p3 = __builtin_bit_cast(unsigned, l);
+}
+
+// Swizzle of the four 16-byte chunks (8 k each) of a 64-byte LDS row: chunk c of row r lives at c ^ G[(r >> 2) & 3],
+// G = {0,2,3,1}.  With ds_read_b128's lane groups ({0-3,12-15,20-27}, ...) the 16 fragment reads of a group then fall
+// on 16 different 16-byte slots of the 256-byte bank row, and ds_write_b64 of whole rows is conflict-free too.
+__device__ __forceinline__ int x3_chunk(int r, int c) { return c ^ ((0x1320 >> (((r >> 2) & 3) * 4)) & 3); }
+
+template <int NT, bool VEC4>
+__global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
+  constexpr int XT = 512;                          // 8 waves x 32 rows: one W tile (and its split) serves 256 rows
+  constexpr int BM = 256, KT = 32, RS = KT;       // LDS rows of 32 bf16 (64 B), 16-byte chunks XOR-swizzled (x3_chunk)
+  constexpr int NW = NT * 16;
+  constexpr int WPAIRS = (KT / 2 * NW + XT - 1) / XT;  // (k, k+1) pairs of one column per thread
+  __shared__ __align__(16) unsigned short Ap[3][BM * RS];
+  __shared__ __align__(16) unsigned short Wp[3][NW * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * NW;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = (p.Kc + KT - 1) / KT;
+  const int total = p.nterms * ktiles;
+
+  float ra[16], rw[2 * WPAIRS];
+  auto load_tile = [&](int ti) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
+    const float* __restrict__ A = p.a[term];
+    const int64_t lda = p.lda[term];
+    const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 64, kk = (tid & 7) * 4;
+        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+        ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
+      }
+    } else {      // thread = (row, k pair)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int row = (tid >> 4) + h * 32, kk = (tid & 15) * 2;
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = (m0 + row < p.M) && (k0 + kk + j < p.Kc);
+          const float v = A[proj_row_off(p, rr, lda) + (ok ? k0 + kk + j : 0)];
+          ra[h * 2 + j] = ok ? v : 0.f;
+        }
+      }
+    }
+    {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        const int idx = min(tid + h * XT, KT / 2 * NW - 1);
+        const int cc = idx % NW, kk = (idx / NW) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = (k0 + kk + j < p.Kc) && (n0 + cc < p.N);
+          const float v = Wt[(int64_t)(ok ? k0 + kk + j : 0) * p.N + (ok ? n0 + cc : 0)];
+          rw[h * 2 + j] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+  auto store_tile = [&]() {      // split into the three bf16 planes on the way into LDS
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 64, kk = (tid & 7) * 4;
+        unsigned a1, a2, a3, b1, b2, b3;
+        split3(ra[h * 4 + 0], ra[h * 4 + 1], a1, a2, a3);
+        split3(ra[h * 4 + 2], ra[h * 4 + 3], b1, b2, b3);
+        const int o = row * RS + x3_chunk(row, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<uint2*>(&Ap[0][o]) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(&Ap[1][o]) = make_uint2(a2, b2);
+        *reinterpret_cast<uint2*>(&Ap[2][o]) = make_uint2(a3, b3);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int row = (tid >> 4) + h * 32, kk = (tid & 15) * 2;
+        unsigned a1, a2, a3;
+        split3(ra[h * 2 + 0], ra[h * 2 + 1], a1, a2, a3);
+        const int o = row * RS + x3_chunk(row, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<unsigned*>(&Ap[0][o]) = a1;
+        *reinterpret_cast<unsigned*>(&Ap[1][o]) = a2;
+        *reinterpret_cast<unsigned*>(&Ap[2][o]) = a3;
+      }
+    }
+    {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {       // W tile transposed: [column][k], so a fragment's 8 k are contiguous
+        const int idx = tid + h * XT;
+        if (idx >= KT / 2 * NW) continue;
+        const int cc = idx % NW, kk = (idx / NW) * 2;
+        unsigned w1, w2, w3;
+        split3(rw[h * 2 + 0], rw[h * 2 + 1], w1, w2, w3);
+        const int o = cc * RS + x3_chunk(cc, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<unsigned*>(&Wp[0][o]) = w1;
+        *reinterpret_cast<unsigned*>(&Wp[1][o]) = w2;
+        *reinterpret_cast<unsigned*>(&Wp[2][o]) = w3;
+      }
+    }
+  };
+
+  load_tile(0);
+  const int frag = (lane & 15) * RS + x3_chunk(lane & 15, lane >> 4) * 8;   // this lane's 8 consecutive k of row / column (lane & 15)
+  for (int ti = 0; ti < total; ++ti) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (ti + 1 < total) load_tile(ti + 1);
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[r][pl] = *reinterpret_cast<const bf16x8*>(&Ap[pl][(wave * 32 + r * 16) * RS + frag]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 w[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8*>(&Wp[pl][(nt * 16) * RS + frag]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {      // smallest terms first
+        f32x4 c = acc[r][nt];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][2], w[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[0], c, 0, 0, 0);
+        acc[r][nt] = c;
+      }
+    }
+  }
+  // ---- epilogue
+  if constexpr (NT <= 4) {
+    if (p.vec_epilogue) {
+      // accumulators -> wave-private scratch (the A planes are free now) -> float4 rows: coalesced bias loads, 16-byte stores
+      constexpr int ES = NW + 4;                       // scratch row stride in floats
+      constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
+      __syncthreads();                                 // every wave is done reading the last tile's planes
+      float* my = reinterpret_cast<float*>(&Ap[0][0]) + wave * (16 * ES);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * ES + nt * 16 + (lane & 15)] = acc[r][nt][i];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+          const int64_t m = m0 + wave * 32 + r * 16 + row;
+          const int col = n0 + seg;
+          if (m >= p.M || col >= p.N) continue;
+          float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
+          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          if (p.bias_kind && col < p.bias_cols) {
+            const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
+          if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+          *o = v;
+        }
+      }
+      return;
+    }
+  }
+  const int col_l = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wave * 32 + r * 16 + (lane >> 4) * 4 + i;
+      if (m >= p.M) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + col_l;
+        if (col >= p.N) continue;
+        float v = acc[r][nt][i];
+        if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+        else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+        float* o = p.out + orow * p.ldo + col;
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
+// ---- bf16x3, second form (16-byte aligned operands): a wave's A rows are used by that wave only, so its A fragments
+// go global -> registers -> split -> MFMA operand with no LDS round trip and no barrier; only the W tile (shared by the
+// 8 waves) is split into LDS, double-buffered, ONE barrier per 32-k tile.  A lane loads the 8 consecutive k of its row
+// as two float4 (the four k groups of a row are adjacent: whole 128-byte lines per row).
+template <int NT>
+__global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
+  constexpr int XT = 512, BM = 256, KT = 32, RS = KT;
+  constexpr int NW = NT * 16;
+  constexpr int WPAIRS = (KT / 2 * NW + XT - 1) / XT;
+  constexpr int WBUF = 3 * NW * RS;                                   // bf16 elements of one W buffer (3 planes)
+  constexpr int ES = NW + 4;                                          // epilogue scratch row stride (floats)
+  constexpr int LDS_BYTES = (2 * WBUF * 2 > 8 * 16 * ES * 4) ? 2 * WBUF * 2 : 8 * 16 * ES * 4;
+  __shared__ __align__(16) unsigned char lds_raw[LDS_BYTES];
+  unsigned short* Wp = reinterpret_cast<unsigned short*>(lds_raw);    // [2][3][NW * RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * NW;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = (p.Kc + KT - 1) / KT;
+  const int total = p.nterms * ktiles;
+  // per-lane, tile-invariant parts of every address (the loop below adds only wave-uniform tile offsets: the vector ALU
+  // is the co-bottleneck of this kernel -- an MFMA holds vector issue for 8 of its 16 cycles)
+  int64_t arow[2];                                   // element offset of this lane's 8 k inside row r (without lda * row: see aoff)
+  int64_t rowc[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int64_t m = m0 + wave * 32 + r * 16 + r16;
+    rowc[r] = m < p.M ? m : p.M - 1;                 // rows past the end re-read the last row; their results are never stored
+    arow[r] = 0;
+  }
+  int wsrc[WPAIRS], wdst[WPAIRS], wkk[WPAIRS];
+  bool wcol[WPAIRS];
+#pragma unroll
+  for (int h = 0; h < WPAIRS; ++h) {
+    const int idx = min(tid + h * XT, KT / 2 * NW - 1);
+    const int cc = idx % NW, kk = (idx / NW) * 2;
+    wkk[h] = kk;
+    wcol[h] = (tid + h * XT < KT / 2 * NW) && (n0 + cc < p.N);
+    wsrc[h] = kk * p.N + (n0 + cc < p.N ? n0 + cc : 0);
+    wdst[h] = cc * RS + x3_chunk(cc, kk >> 3) * 8 + (kk & 7);
+  }
+  float ra[2][8], rw[2 * WPAIRS];
+  auto load_a = [&](int ti, float (&dst)[2][8]) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;           // wave-uniform
+    const float* __restrict__ A = p.a[term] + k0 + kg * 8;
+    const int64_t lda = p.lda[term];
+    if (k0 + KT <= p.Kc) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 v = *reinterpret_cast<const float4*>(A + rowc[r] * lda + h * 4);
+          dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
+        }
+    } else {                                                         // last k tile of a term: k past Kc reads as zero
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = k0 + kg * 8 + h * 4 < p.Kc;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) v = *reinterpret_cast<const float4*>(A + rowc[r] * lda + h * 4);
+          dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
+        }
+    }
+  };
+  auto load_w = [&](int ti) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
+    const float* __restrict__ Wt = p.W + ((int64_t)term * p.Kc + k0) * p.N;
+    if (k0 + KT <= p.Kc) {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        rw[h * 2 + 0] = wcol[h] ? Wt[wsrc[h]] : 0.f;
+        rw[h * 2 + 1] = wcol[h] ? Wt[wsrc[h] + p.N] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        rw[h * 2 + 0] = (wcol[h] && k0 + wkk[h] < p.Kc) ? Wt[wsrc[h]] : 0.f;
+        rw[h * 2 + 1] = (wcol[h] && k0 + wkk[h] + 1 < p.Kc) ? Wt[wsrc[h] + p.N] : 0.f;
+      }
+    }
+  };
+  auto store_w = [&](int buf) {            // W tile transposed [column][k], split into the three planes
+    unsigned short* W0 = Wp + buf * WBUF;
+#pragma unroll
+    for (int h = 0; h < WPAIRS; ++h) {
+      if (tid + h * XT >= KT / 2 * NW) continue;
+      unsigned w1, w2, w3;
+      split3(rw[h * 2 + 0], rw[h * 2 + 1], w1, w2, w3);
+      *reinterpret_cast<unsigned*>(&W0[wdst[h]]) = w1;
+      *reinterpret_cast<unsigned*>(&W0[NW * RS + wdst[h]]) = w2;
+      *reinterpret_cast<unsigned*>(&W0[2 * NW * RS + wdst[h]]) = w3;
+    }
+  };
+  load_a(0, ra);
+  load_w(0);
+  store_w(0);
+  __syncthreads();
+  const int frag = r16 * RS + x3_chunk(r16, kg) * 8;
+  for (int ti = 0; ti < total; ++ti) {
+    float rn[2][8];
+    const bool more = ti + 1 < total;
+    if (more) { load_a(ti + 1, rn); load_w(ti + 1); }
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned pl[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(ra[r][2 * j], ra[r][2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        a[r][q] = __builtin_bit_cast(bf16x8, u32x4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+      }
+    }
+    const unsigned short* W0 = Wp + (ti & 1) * WBUF;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 w[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) w[q] = *reinterpret_cast<const bf16x8*>(&W0[q * NW * RS + (nt * 16) * RS + frag]);
+      // smallest terms first; the two row tiles alternate so that consecutive MFMAs are independent
+      f32x4 c0 = acc[0][nt], c1 = acc[1][nt];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][2], w[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][2], w[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], w[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], w[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[2], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[2], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], w[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], w[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[0], c1, 0, 0, 0);
+      acc[0][nt] = c0; acc[1][nt] = c1;
+    }
+    if (more) {
+      store_w((ti + 1) & 1);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ra[r][j] = rn[r][j];
+    }
+    __syncthreads();
+  }
+  // ---- epilogue
+  if constexpr (NT <= 4) {
+    if (p.vec_epilogue) {
+      constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
+      float* my = reinterpret_cast<float*>(lds_raw) + wave * (16 * ES);     // the loop ended with a barrier: W buffers are free
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) my[(kg * 4 + i) * ES + nt * 16 + r16] = acc[r][nt][i];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+          const int64_t m = m0 + wave * 32 + r * 16 + row;
+          const int col = n0 + seg;
+          if (m >= p.M || col >= p.N) continue;
+          float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
+          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          if (p.bias_kind && col < p.bias_cols) {
+            const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
+          if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+          *o = v;
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wave * 32 + r * 16 + kg * 4 + i;
+      if (m >= p.M) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + r16;
+        if (col >= p.N) continue;
+        float v = acc[r][nt][i];
+        if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+        else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+        float* o = p.out + orow * p.ldo + col;
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
+// W-resident variant for the common case where the whole folded weight fits in LDS (nterms*Kc*N*4 <= 80 KB).
+// 512 threads = 8 waves; the block loads W once, then every wave streams its own 32-row tiles:
+//   global (float4, row-contiguous) -> registers -> wave-private LDS scratch [32][66] -> MFMA A fragments,
+// with the next piece's global loads issued before the current piece's MFMAs.  No block barrier in the loop.
+// W image: [term][k padded to 4][NT*16 columns], odd k rows have their 16-column halves swapped when the row
+// is a multiple of 32 floats, so the B-fragment read (k, k+1 in one 32-lane group) is conflict-free.
+constexpr int kResMaxThreads = 1024;
+constexpr int kResKT = 64;             // floats of K per staged piece
+constexpr int kResAS = kResKT + 2;     // scratch row stride (== 2 mod 32)
+constexpr int kResScratchFloats = 8 * 32 * kResAS;   // wave-private A scratch in total: (512*2/RT threads / 64) waves x 16*RT rows
+constexpr int kResMaxWBytes = 80 * 1024;
+
+template <int NT>
+__device__ __forceinline__ int w_col(int k, int n) {
+  if constexpr ((NT & 1) == 0) return n ^ ((k & 1) << 4);
+  else return n;
+}
+
+// RT = 16-row MFMA tiles per wave: 2 -> 8 waves x 32 rows (B fragments shared by two tiles), 1 -> 16 waves x 16 rows
+// (4 waves per SIMD to cover LDS / global latency).
+template <int NT, bool VEC4, int RT>
+__global__ __launch_bounds__(1024 / RT) void project_resident_kernel(const ProjParams p, const int kc4, const int64_t ntiles) {
+  constexpr int kResThreads = 1024 / RT, kResWaves = kResThreads / 64, kResRows = 16 * RT;
+  extern __shared__ __align__(16) float smem[];
+  constexpr int NW = NT * 16;
+  float* Ws = smem;                                         // [nterms*kc4][NW]
+  const int ktot = p.nterms * kc4;
+  float* scratch = smem + (size_t)ktot * NW;                // [kResWaves][kResRows*kResAS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * NW;
+  // ---- W -> LDS (once)
+  for (int idx = tid; idx < ktot * NW; idx += kResThreads) {
+    const int kk = idx / NW, cc = idx % NW;
+    const int term = kk / kc4, kin = kk % kc4;
+    float v = 0.f;
+    if (kin < p.Kc && n0 + cc < p.N) v = p.W[((int64_t)term * p.Kc + kin) * p.N + n0 + cc];
+    Ws[kk * NW + w_col<NT>(kk, cc)] = v;
+  }
+  __syncthreads();
+  float* my = scratch + wave * (kResRows * kResAS);
+  const int npieces = (p.Kc + kResKT - 1) / kResKT;
+  const int total_pieces = p.nterms * npieces;
+
+  for (int64_t tile = (int64_t)blockIdx.x * kResWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kResWaves) {
+    const int64_t m0 = tile * kResRows;
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NRA = VEC4 ? 4 * RT : kResRows, NVA = VEC4 ? 4 : 1;
+    float raA[NRA][NVA], raB[NRA][NVA];   // two pieces in flight (global -> registers) ahead of the one being multiplied
+    // loads are unconditional (clamped address, value masked afterwards): no branch per load
+    auto load_piece = [&](int pc, float (&ra)[NRA][NVA]) {
+      const int term = pc / npieces, k0 = (pc % npieces) * kResKT;
+      const float* __restrict__ A = p.a[term];
+      const int64_t lda = p.lda[term];
+      if constexpr (VEC4) {
+#pragma unroll
+        for (int i = 0; i < 4 * RT; ++i) {
+          const int idx = lane + 64 * i, row = idx >> 4, kk = (idx & 15) * 4;
+          const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+          const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+          const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+          const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+          ra[i][0] = ok ? v.x : 0.f; ra[i][1] = ok ? v.y : 0.f; ra[i][2] = ok ? v.z : 0.f; ra[i][3] = ok ? v.w : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kResRows; ++i) {
+          const bool ok = (m0 + i < p.M) && (k0 + lane < p.Kc);
+          const int64_t rr = (m0 + i < p.M) ? m0 + i : p.M - 1;
+          const int kc = (k0 + lane < p.Kc) ? k0 + lane : 0;
+          const float v = A[proj_row_off(p, rr, lda) + kc];
+          ra[i][0] = ok ? v : 0.f;
+        }
+      }
+    };
+    auto store_piece = [&](const float (&ra)[NRA][NVA]) {
+      if constexpr (VEC4) {
+#pragma unroll
+        for (int i = 0; i < 4 * RT; ++i) {
+          const int idx = lane + 64 * i, row = idx >> 4, kk = (idx & 15) * 4;
+          float2* d = reinterpret_cast<float2*>(&my[row * kResAS + kk]);
+          d[0] = make_float2(ra[i][0], ra[i][1]);
+          d[1] = make_float2(ra[i][2], ra[i][3]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kResRows; ++i) my[i * kResAS + lane] = ra[i][0];
+      }
+    };
+    const float* a0 = &my[(lane & 15) * kResAS + (lane >> 4)];
+    // w_even / w_odd: this lane's row of the W image with the (lane-constant) column swizzle of even / odd
+    // column tiles folded in: (nt*16 + c) ^ sw == nt*16 + c + (nt even ? sw : -sw)
+    auto kstep = [&](int ks, const float* w_even, const float* w_odd) {
+      float av[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) av[r] = a0[r * 16 * kResAS + ks * 4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = ((nt & 1) ? w_odd : w_even)[ks * 4 * NW + nt * 16];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv, acc[r][nt], 0, 0, 0);
+      }
+    };
+
+    auto compute_piece = [&](int pc) {
+      const int term = pc / npieces, k0 = (pc % npieces) * kResKT;
+      const int ksteps = (min(kResKT, p.Kc - k0) + 3) >> 2;
+      const int kbase = term * kc4 + k0 + (lane >> 4);
+      // (kbase + 4*ks) & 1 == kbase & 1: the column swizzle is the same for every k-step of this lane
+      const int sw = ((NT & 1) == 0) ? ((kbase & 1) << 4) : 0;
+      const float* w_even = &Ws[kbase * NW + (lane & 15) + sw];
+      const float* w_odd = &Ws[kbase * NW + (lane & 15) - sw];
+      if (ksteps == kResKT / 4) {          // full piece: straight-line code so LDS reads run ahead of the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < kResKT / 4; ++ks) kstep(ks, w_even, w_odd);
+      } else {
+        for (int ks = 0; ks < ksteps; ++ks) kstep(ks, w_even, w_odd);
+      }
+    };
+    load_piece(0, raA);
+    if (total_pieces > 1) load_piece(1, raB);
+    for (int pc = 0; pc < total_pieces; pc += 2) {
+      store_piece(raA);                    // previous piece's fragment reads were issued before (in-order LDS)
+      if (pc + 2 < total_pieces) load_piece(pc + 2, raA);
+      compute_piece(pc);
+      if (pc + 1 < total_pieces) {
+        store_piece(raB);
+        if (pc + 3 < total_pieces) load_piece(pc + 3, raB);
+        compute_piece(pc + 1);
+      }
+    }
+    // ---- epilogue
+    if (p.vec_epilogue) {
+      // accumulators -> wave scratch (row-major) -> float4 rows: coalesced bias loads and 16-byte stores
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) my[(r * 16 + (lane >> 4) * 4 + i) * kResAS + nt * 16 + (lane & 15)] = acc[r][nt][i];
+      constexpr int SEGS = NW / 4;                        // float4 per row
+      constexpr int ITER = (kResRows * SEGS) / 64;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+        const int64_t m = m0 + row;
+        const int col = n0 + seg;
+        if (m >= p.M || col >= p.N) continue;
+        const float2 lo = *reinterpret_cast<const float2*>(&my[row * kResAS + seg]);
+        const float2 hi = *reinterpret_cast<const float2*>(&my[row * kResAS + seg + 2]);
+        float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
+        const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+        if (p.bias_kind && col < p.bias_cols) {
+          const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
+        if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+        *o = v;
+      }
+    } else {
+      const int col_l = lane & 15;
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t m = m0 + r * 16 + (lane >> 4) * 4 + i;
+          if (m >= p.M) continue;
+          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + nt * 16 + col_l;
+            if (col >= p.N) continue;
+            float v = acc[r][nt][i];
+            if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+            else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+            float* o = p.out + orow * p.ldo + col;
+            if (p.accumulate) v += *o;
+            *o = v;
+          }
+        }
+    }
+  }
+}
+
+// ---- narrow contraction (sum of Kc over the terms <= 16, e.g. one input channel per time step): the projection is a
+// pure streaming write of (M, N) with a handful of scalars read per row, so it runs on the vector ALU.  W and the
+// block's A values sit in LDS (A staged with coalesced loads, stored so that a thread's 4 rows are one 16-byte read);
+// a thread owns 4 output columns of 4 rows per step; stores are whole 16-byte pieces of an output row.
+// k-ordered fmaf chain per output, like the exact MFMA kernels.
+constexpr int kNarrowMaxK = 16;
+__global__ __launch_bounds__(kBlock) void project_narrow_kernel(const ProjParams p, int iters) {
+  extern __shared__ float sW[];   // (ktot, N) weights, then (ktot, iters, RP, 4) A values
+  const int ktot = p.nterms * p.Kc;
+  const int L = p.N >> 2, RP = kBlock / L;
+  const int rows_per_block = RP * 4 * iters;
+  float* __restrict__ sA = sW + ktot * p.N;
+  const int64_t mb0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t mend = (mb0 + rows_per_block < p.M) ? mb0 + rows_per_block : p.M;
+  const int nrows = (int)(mend - mb0);
+  for (int i = threadIdx.x; i < ktot * p.N; i += kBlock) sW[i] = p.W[i];
+  for (int t = 0; t < p.nterms; ++t) {
+    const float* __restrict__ at = p.a[t] + mb0 * p.lda[t];
+    const int64_t ld = p.lda[t];
+    for (int i = threadIdx.x; i < nrows * p.Kc; i += kBlock) {
+      const int l = i / p.Kc, kc = i - l * p.Kc;                 // local row = (it * 4 + j) * RP + r
+      const int it = l / (4 * RP), rem = l - it * 4 * RP, j = rem / RP, r = rem - j * RP;
+      sA[(((t * p.Kc + kc) * iters + it) * RP + r) * 4 + j] = at[(int64_t)l * ld + kc];
+    }
+  }
+  __syncthreads();
+  const int r_in = threadIdx.x / L, c4 = (threadIdx.x % L) * 4;
+  if (r_in >= RP) return;
+  for (int it = 0; it * 4 * RP < nrows; ++it) {
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+    for (int kk = 0; kk < ktot; ++kk) {
+      const float4 w = *reinterpret_cast<const float4*>(sW + kk * p.N + c4);
+      const float4 a4 = *reinterpret_cast<const float4*>(sA + ((kk * iters + it) * RP + r_in) * 4);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j][0] = fmaf(av[j], w.x, acc[j][0]);
+        acc[j][1] = fmaf(av[j], w.y, acc[j][1]);
+        acc[j][2] = fmaf(av[j], w.z, acc[j][2]);
+        acc[j][3] = fmaf(av[j], w.w, acc[j][3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = mb0 + (it * 4 + j) * RP + r_in;
+      if (m >= mend) continue;
+      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      if (p.bias_kind && c4 < p.bias_cols) {
+        const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + c4);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + c4);
+      if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+      using f4 = __attribute__((ext_vector_type(4))) float;
+      __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(o));   // written once, read by a later kernel
+    }
+  }
+}
