@@ -121,10 +121,36 @@ __device__ __forceinline__ void finish_row(const HopParams& p, int b, int r, int
   }
 }
 
+// Value of lane `lane` of every LPR-lane group (lane is a constant once the caller's loops are unrolled): a DPP row
+// broadcast for 16-lane groups, a quad permute for 4-lane groups, v_readlane for whole-wave groups -- one vector-ALU
+// instruction instead of a trip through the LDS crossbar (ds_bpermute) in the entry -> gather chain.
+template <int LPR>
+__device__ __forceinline__ int group_bcast(int v, int lane) {
+  if constexpr (LPR == 64) {
+    return __builtin_amdgcn_readlane(v, lane);
+  } else if constexpr (LPR == 16) {
+#define TGCN_RB(N) case N: return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false);   /* row_newbcast:N */
+    switch (lane) {
+      TGCN_RB(0) TGCN_RB(1) TGCN_RB(2) TGCN_RB(3) TGCN_RB(4) TGCN_RB(5) TGCN_RB(6) TGCN_RB(7)
+      TGCN_RB(8) TGCN_RB(9) TGCN_RB(10) TGCN_RB(11) TGCN_RB(12) TGCN_RB(13) TGCN_RB(14) default: return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xF, 0xF, false);
+    }
+#undef TGCN_RB
+  } else if constexpr (LPR == 4) {
+    switch (lane) {
+      case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, false);    // quad_perm:[0,0,0,0]
+      case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xF, 0xF, false);
+      case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xF, 0xF, false);
+      default: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, false);
+    }
+  } else {
+    return __shfl(v, lane, LPR);
+  }
+}
+
 // Sum of val_e * X[col_e, c0..c0+VEC) over stored entries [e0[rr], e1[rr]) of R rows (or segments) at once, by one
 // group of LPR lanes.  Per row the group reads LPR entries with one coalesced 8-byte load per lane and hands them
-// round with in-register shuffles; gathers are issued U at a time per row, so R*U 16-byte loads are in flight per
-// lane.  R > 1 keeps R independent rowptr -> entry -> gather chains going, which is what low-degree rows on wide
+// round with in-register broadcasts (group_bcast); gathers are issued U at a time per row, so R*U 16-byte loads are in
+// flight per lane.  R > 1 keeps R independent rowptr -> entry -> gather chains going, which is what low-degree rows on wide
 // operands need (measured on the mesh config); entries are summed in stored order: deterministic.
 template <int LPR, int VEC, int UU, int R, int NTM>
 __device__ __forceinline__ void accum_multi(const tgcn_edge* __restrict__ ev, const int (&e0)[R], const int (&e1)[R], int t,
@@ -146,26 +172,28 @@ __device__ __forceinline__ void accum_multi(const tgcn_edge* __restrict__ ev, co
       cnt[rr] = min(LPR, max(0, e1[rr] - e0[rr] - off));
       cmax = max(cmax, cnt[rr]);
     }
-    for (int j0 = 0; j0 < LPR; j0 += U) {
-      if (j0 >= cmax) break;
-      float xv[R][U][VEC];
-      float vv[R][U];
 #pragma unroll
-      for (int rr = 0; rr < R; ++rr)
+    for (int j0 = 0; j0 < LPR; j0 += U) {        // fully unrolled: the broadcast lane is an immediate
+      if (j0 < cmax) {
+        float xv[R][U][VEC];
+        float vv[R][U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int c = __shfl(my_c[rr], j0 + u, LPR);
-          vv[rr][u] = __shfl(my_v[rr], j0 + u, LPR);   // 0 past the end of the row
+        for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) xv[rr][u][i] = 0.f;
-          if (j0 + u < cnt[rr]) load_vec<VEC>(Xc + (int64_t)c * ldx, xv[rr][u]);
-        }
+          for (int u = 0; u < U; ++u) {
+            const int c = group_bcast<LPR>(my_c[rr], j0 + u);
+            vv[rr][u] = __int_as_float(group_bcast<LPR>(__float_as_int(my_v[rr]), j0 + u));   // 0 past the end of the row
 #pragma unroll
-      for (int rr = 0; rr < R; ++rr)
+            for (int i = 0; i < VEC; ++i) xv[rr][u][i] = 0.f;
+            if (j0 + u < cnt[rr]) load_vec<VEC>(Xc + (int64_t)c * ldx, xv[rr][u]);
+          }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[rr][i] = fmaf(vv[rr][u], xv[rr][u][i], acc[rr][i]);
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[rr][i] = fmaf(vv[rr][u], xv[rr][u][i], acc[rr][i]);
+      }
     }
   }
 }
@@ -302,11 +330,11 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
   return g;
 }
 
-template <int LPR, int VEC, int U, int R>
+template <int LPR, int VEC, int U, int R, int NTM = 0>
 inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
   constexpr int GPB = kBlock / LPR;
   grid.x = (unsigned)(p.nblk + (p.nseg + GPB * R - 1) / (GPB * R));
-  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, 0>), grid, dim3(kBlock), 0, st, p);
+  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, NTM>), grid, dim3(kBlock), 0, st, p);
 }
 
 // developer variants of the two float4 shapes that matter for the benchmarks (tools/hop_bench.py)
