@@ -496,13 +496,15 @@ def test_backward_vs_dense_autograd(cls, small, shape, gpu_device, monkeypatch):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy().reshape(a.shape)) <= 2e-5
 
 
-@pytest.mark.parametrize("cls,n,pool", [("TGCNCheb_H", 784, 4), ("GCNCheb", 400, 2), ("ChebConv", 5000, 4), ("GCNCheb64", 2048, 4)])
+@pytest.mark.parametrize("cls,n,pool", [("TGCNCheb_H", 784, 4), ("GCNCheb", 400, 2), ("ChebConv", 5000, 4), ("GCNCheb64", 2048, 4),
+                                        ("TGCNCheb_H", 148, 4), ("GCNCheb", 64, 2)])
 def test_fused_relu_pool_matches_unfused(cls, n, pool, gpu_device):
-    """cheb_relu_pool(layer, x) == gcn_pool*(relu(layer(x))) in value and in all gradients (small-graph fused kernel
-    for the first two, layer + one relu/pool pass for the larger ones)."""
+    """cheb_relu_pool(layer, x) == gcn_pool*(relu(layer(x))) in value and in all gradients (small-graph fused kernels
+    for the first two, layer + one relu/pool pass for the larger ones and for the dense operands n = 148 / 64, whose
+    layer runs on the matrix pipe)."""
     import tgcn_amd
     rng = np.random.default_rng(n)
-    row, col, val = _random_graph(n, 5, rng)
+    row, col, val = _random_graph(n, 100 if n in (148, 64) else 5, rng)
     A = O.coo_to_csr(row, col, np.abs(val), n)
     A = ((A + A.T) > 0).astype(np.float32)
     A.setdiag(0)

@@ -389,7 +389,10 @@ class ChebReluPoolFn(torch.autograd.Function):
         z = torch.empty((q, n // pool, N), dtype=torch.float32, device=x3.device)
         idx = torch.empty((q, n // pool, N), dtype=torch.uint8, device=x3.device)
         L = _lib.lib()
-        if small_path_tile(op, Crow, mode, pool=True):
+        # dense small operands run the layer on the matrix pipe (no fused epilogue there): layer + one relu/pool pass beats
+        # the fused vector-ALU kernel (HCP shape: 136 + 15 us against 330 us)
+        dense_mfma = op.dense is not None and Crow <= 32
+        if small_path_tile(op, Crow, mode, pool=True) and not dense_mfma:
             _lib.check(L.tgcn_cheb_forward_small_pool_f32(_lib.stream_ptr(), C.byref(op.struct), mode, K, q, Crow, N, _lib.ptr(x3),
                                                           _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
                                                           _lib.ptr(z), _lib.ptr(idx)))
