@@ -193,7 +193,9 @@ int tgcn_cheb_forward_small_f32(void* stream, const tgcn_csr* A, int32_t mode, i
 
 /* Backward of the same shapes.  The input gradient is the forward kernel itself on the transposed operand
  * (dx = sum_j (L^T)^j g W_j^T: call tgcn_cheb_forward_small_f32 with A = L^T, x = g, W = the (K, N, C) transposed
- * working-basis weight, no bias).  The weight gradient needs the basis: tgcn_cheb_basis_small_f32 writes terms
+ * working-basis weight, no bias).  The weight gradient needs the basis autograd would recompute through
+ * _chebyshev / _time_chebyshev (gcn.py:52-79,126-154,208-237; true recurrence gcn.py:420-432,519-528):
+ * tgcn_cheb_basis_small_f32 writes terms
  * k = 1 .. K-1 of the (K, q, n, C) stack in ONE launch (mode 0: monomials L^k x, the basis of the folded weight;
  * mode 1: Chebyshev T_k x); term 0 is x itself and is not copied.  Feed the terms to tgcn_cheb_wgrad_f32.
  * _supported returns the channel tile (16 / 8 / 4) or 0 when the operand does not fit in LDS. */
