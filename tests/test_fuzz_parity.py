@@ -41,6 +41,50 @@ for _ in range(80):
                       bias=bool(_rng.integers(0, 2)), seed=int(_rng.integers(1 << 30))))
 
 
+def _check_forward(case):
+    """Forward of one random case against the oracle (shared by the sweep below and the tuning-switch test)."""
+    import tgcn_amd
+    rng = np.random.default_rng(case["seed"])
+    n, q, K, H, f, g, cls = (case[k] for k in ("n", "q", "K", "H", "f", "g", "cls"))
+    A = _graph(n, case["kind"], rng)
+    coo = A.tocoo()
+    ei = np.stack([coo.row, coo.col]).astype(np.int64)
+    timed = cls in ("TGCNCheb_H", "ChebTimeConv")
+    torch.manual_seed(case["seed"] % 1000)
+    if cls in ("ChebConv", "ChebTimeConv"):
+        layer = (tgcn_amd.ChebTimeConv(f, g, K, H, bias=case["bias"]) if timed else tgcn_amd.ChebConv(f, g, K, bias=case["bias"])).cuda()
+        L = None
+    else:
+        L = O.rescaled_laplacian(A.astype(np.float32), lmax=2)
+        ctor = dict(GCNCheb=tgcn_amd.GCNCheb, TGCNCheb=tgcn_amd.TGCNCheb)
+        layer = (tgcn_amd.TGCNCheb_H(L, f, g, K, H, bias=case["bias"]) if timed else ctor[cls](L, f, g, K, bias=case["bias"])).cuda()
+    x = rng.standard_normal((q, n, H, f) if timed else (q, n, f)).astype(np.float32)
+    W = layer.weight.detach().cpu().numpy()
+    b = layer.bias.detach().cpu().numpy() if case["bias"] else None
+    xt = torch.tensor(x, device="cuda")
+    with torch.no_grad():
+        out = layer(xt, torch.tensor(ei, device="cuda")) if L is None else layer(xt)
+    ref = dict(GCNCheb=lambda: O.gcn_cheb_forward(L, x, W, b), TGCNCheb=lambda: O.tgcn_cheb_forward(L, x, W, b),
+               TGCNCheb_H=lambda: O.tgcn_cheb_h_forward(L, x, W, b), ChebConv=lambda: O.cheb_conv_forward(x, ei, None, W, b),
+               ChebTimeConv=lambda: O.cheb_time_conv_forward(x, ei, None, W, b))[cls]()
+    assert rel_err(out.cpu().numpy(), ref) <= TOL, case
+
+
+@pytest.mark.parametrize("key,value", [("small_dense", 0), ("small_narrow", 0), ("project_variant", 1), ("project_variant", 3),
+                                       ("project_variant", 4), ("x3_form", 1), ("overlap", 1), ("hop_variant", 1)])
+def test_tuning_switches_keep_the_result(key, value, gpu_device):
+    """Every tgcn_set_tuning switch selects another kernel for the same arithmetic: the first 24 random cases must still
+    match the oracle with the switch thrown."""
+    from tgcn_amd import _lib
+    _lib.check(_lib.lib().tgcn_set_tuning(key.encode(), value))
+    try:
+        for case in CASES[:24]:
+            _check_forward(case)
+    finally:
+        default = {"small_dense": 1, "small_narrow": 1, "project_variant": 0, "x3_form": 2, "overlap": 0, "hop_variant": 0}[key]
+        _lib.check(_lib.lib().tgcn_set_tuning(key.encode(), default))
+
+
 @pytest.mark.parametrize("case", CASES, ids=["%s-n%d-%s-q%d-K%d-H%d-f%d-g%d" % (c["cls"], c["n"], c["kind"], c["q"], c["K"], c["H"], c["f"], c["g"]) for c in CASES])
 def test_random_module_vs_oracle(case, gpu_device):
     import tgcn_amd
