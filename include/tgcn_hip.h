@@ -98,7 +98,15 @@ int tgcn_abi_version(void);
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 
-/* Developer knob for A/B runs (tools/hop_bench.py).  key "hop_variant": 0 = shipped kernel. */
+/* Developer switches for A/B runs (tools/*_bench.py; every one is checked against the oracle in
+ * tests/test_fuzz_parity.py).  Process-wide, same arithmetic, another kernel; returns TGCN_ERR_INVALID for unknown keys.
+ *   "hop_variant"     0 shipped hop kernel; 1.. alternative unroll / row-interleave shapes of hop.h
+ *   "project_variant" 0 auto; 1 exact-fp32 streaming-W; 2 exact-fp32 W-resident with 16-row wave tiles; 3 bf16x3 always;
+ *                     4 exact-fp32 auto; 5 vector-ALU narrow kernel wherever it applies
+ *   "x3_form"         2 (default) bf16x3 with A fragments from registers for >= 96 output columns; 1 both operands via LDS
+ *   "overlap"         1: projection of pass i on a side stream under the hops of pass i+1 (default 0)
+ *   "small_dense"     0: dense small operands stay on the vector-ALU one-launch kernels (default 1: matrix pipe)
+ *   "small_narrow"    0: C <= 4 inputs use the output-side one-launch kernel (default 1: input-side recursion) */
 int tgcn_set_tuning(const char* key, int32_t value);
 
 /* Geometry the host needs to build a schedule / size scratch for a row length C (floats).
