@@ -98,7 +98,7 @@ int tgcn_abi_version(void);
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 
-/* Developer switches for A/B runs (tools/*_bench.py; every one is checked against the oracle in
+/* Developer switches for A/B runs (tools/hop_bench.py, tools/proj_bench.py; every one is checked against the oracle in
  * tests/test_fuzz_parity.py).  Process-wide, same arithmetic, another kernel; returns TGCN_ERR_INVALID for unknown keys.
  *   "hop_variant"     0 shipped hop kernel; 1.. alternative unroll / row-interleave shapes of hop.h
  *   "project_variant" 0 auto; 1 exact-fp32 streaming-W; 2 exact-fp32 W-resident with 16-row wave tiles; 3 bf16x3 always;

@@ -313,10 +313,11 @@ int tgcn_cheb_wgrad_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.nblocks = wgrad_blocks(M);
   p.rows_per_block = wgrad_rows_per_block(M);
   const int ctiles = (Kc + 15) / 16;
-  if ((N + 63) / 64 > 65535 || ctiles > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "wgrad: Kc=%d N=%d too wide", Kc, N);
+  const int tgroups = (nterms + kWgTerms - 1) / kWgTerms;
+  if ((N + 63) / 64 > 65535 || (int64_t)ctiles * tgroups > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "wgrad: Kc=%d N=%d too wide", Kc, N);
   hipStream_t st = (hipStream_t)stream;
   { ProfScope ps(TGCN_PROF_WGRAD, st);
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(p.nblocks, (N + 63) / 64, ctiles), dim3(64), 0, st, p); }
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(p.nblocks, (N + 63) / 64, ctiles * tgroups), dim3(64), 0, st, p); }
   { ProfScope ps(TGCN_PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)nterms * Kc * N + 63) / 64)), dim3(1024), 0, st, p); }
   TGCN_CHECK_LAUNCH("tgcn_cheb_wgrad_f32");

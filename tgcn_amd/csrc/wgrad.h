@@ -22,7 +22,7 @@ struct WgradParams {
 
 constexpr int kWgTerms = 5;   // terms accumulated at once per wave (register budget: 5 * 4 tiles * 4 regs)
 
-// One wave per (row block, 64-column tile of G, 16-row tile of the weight): dW_t tile = A_t^T G over the block's rows
+// One wave per (row block, 64-column tile of G, 16-row tile of the weight, group of kWgTerms terms): dW_t tile = A_t^T G over the block's rows
 // on the fp32 MFMA (k = 4 rows per instruction), fragments straight from global memory, kWgUnroll steps of loads in
 // flight.  Row blocks are small (>= 64 rows) so that a few thousand waves cover even the q*n ~ 50 k rows of the
 // small-graph configs; the per-block partials are folded in block order by wgrad_reduce_kernel (deterministic).
@@ -33,10 +33,13 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(const WgradParams p) 
   const int64_t m_lo = (int64_t)blockIdx.x * p.rows_per_block;
   const int64_t m_hi = min(p.M, m_lo + p.rows_per_block);
   const int n0 = blockIdx.y * 64;
-  const int ct = blockIdx.z;
+  const int tgroups = (p.nterms + kWgTerms - 1) / kWgTerms;
+  const int ct = blockIdx.z / tgroups;                     // 16-row tile of the weight
+  const int tg = blockIdx.z % tgroups;                     // group of kWgTerms terms: its own wave, not a serial pass
   float* part = p.partial + (size_t)blockIdx.x * p.nterms * p.Kc * p.N;
   const int c = ct * 16 + r;
-  for (int t0 = 0; t0 < p.nterms; t0 += kWgTerms) {
+  {
+    const int t0 = tg * kWgTerms;
     f32x4 acc[kWgTerms][4];
 #pragma unroll
     for (int t = 0; t < kWgTerms; ++t)
