@@ -13,7 +13,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "bench_lines", "*.jso
     if lines:
         out[os.path.basename(f)[:-5]] = json.loads(lines[-1])
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "bench_lines", "train_*.txt"))):
-    out[os.path.basename(f)[:-4]] = [l for l in open(f).read().splitlines() if "forward" in l]
+    out[os.path.basename(f)[:-4]] = [l for l in open(f).read().splitlines() if "forward" in l or "HCP-style" in l]
 json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_bench_lines.json"), "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict):
