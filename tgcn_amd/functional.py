@@ -8,7 +8,6 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .graph import GraphOperand
 
 SMALL_PATH = True   # developer switch (tools/): route small graphs through the general multi-launch path instead
 MODE_POWER = 0      # dense-L classes: Xt[k] = 2 L^k x - Xt[k-2]  (tgcn/nn/gcn.py:75-78,150-153,233-236)

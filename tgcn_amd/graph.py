@@ -4,7 +4,6 @@ Built ONCE per operand (the reference re-does `L.to(device)` and the degree norm
 tgcn/nn/gcn.py:141,223 and :408-413,505-510) and cached by the modules.  The preparation below is index
 plumbing on torch tensors (sort / cumsum / searchsorted); every flop of the layer runs in libtgcn_hip.so.
 """
-import ctypes as C
 
 import torch
 
