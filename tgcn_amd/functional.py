@@ -30,27 +30,29 @@ def _aligned16(C_row, *tensors):
 
 
 # ----------------------------------------------------------------------------------------- single ops
-def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=None):
-    """One hop:  S = L x;  y = alpha*S + beta*z;  optionally also S.  x: (nb, op.n_cols, C); y, z, S: (nb, op.n, C);
-    any of them may be a strided view as long as the last dim is contiguous.  Returns y (and S when want_p)."""
-    _lib.require_device(x, z)
+def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=None, z2=None, gamma=0.0):
+    """One hop:  S = L x;  y = alpha*S + beta*z (+ gamma*z2);  optionally also S.  x: (nb, op.n_cols, C); y, z, z2, S:
+    (nb, op.n, C); any of them may be a strided view as long as the last dim is contiguous.  Returns y (and S when want_p)."""
+    _lib.require_device(x, z, z2)
     L = _lib.lib()
     assert x.dim() == 3 and x.dtype == torch.float32 and x.shape[1] == op.n_cols, (x.shape, op.n_cols)
     nb, _, Crow = x.shape
     y = torch.empty((nb, op.n, Crow), dtype=torch.float32, device=x.device) if out is None else out
     p = (torch.empty((nb, op.n, Crow), dtype=torch.float32, device=x.device) if p_out is None else p_out) if want_p else None
-    for t in (y, z, p):
+    for t in (y, z, p, z2):
         assert t is None or tuple(t.shape) == (nb, op.n, Crow), (t.shape, (nb, op.n, Crow))
-    al = _aligned16(Crow, x, z, y, p)
+    al = _aligned16(Crow, x, z, y, p, z2)
     sched = op.schedule_for(Crow, al)
     ws_bytes = L.tgcn_csr_hop_workspace_bytes(C.byref(sched.struct), nb, Crow, 1 if al else 0)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     X, Y = _dense(x), _dense(y)
     Z = _dense(z) if z is not None else None
     P = _dense(p) if p is not None else None
-    _lib.check(L.tgcn_csr_hop_f32(_lib.stream_ptr(), C.byref(op.struct), C.byref(sched.struct), nb, Crow, C.byref(X),
-                                  C.byref(Z) if Z is not None else None, float(alpha), float(beta), C.byref(Y),
-                                  C.byref(P) if P is not None else None, _lib.ptr(ws), ws.numel()))
+    Z2 = _dense(z2) if z2 is not None else None
+    _lib.check(L.tgcn_csr_hop2_f32(_lib.stream_ptr(), C.byref(op.struct), C.byref(sched.struct), nb, Crow, C.byref(X),
+                                   C.byref(Z) if Z is not None else None, float(alpha), float(beta),
+                                   C.byref(Z2) if Z2 is not None else None, float(gamma), C.byref(Y),
+                                   C.byref(P) if P is not None else None, _lib.ptr(ws), ws.numel()))
     return (y, p) if want_p else y
 
 
@@ -370,14 +372,11 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs):
         elif K == 1:
             gx = G[0].contiguous()
         else:                                                        # Clenshaw on L^T
-            b1 = torch.zeros((q, n, Crow), dtype=torch.float32, device=g.device)
-            b2 = torch.zeros_like(b1)
-            for k in range(K - 1, 0, -1):
-                t = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0)
-                t.add_(G[k])
+            b1, b2 = G[K - 1], None                                   # b_{K-1} = G_{K-1} (b_K = b_{K+1} = 0)
+            for k in range(K - 2, 0, -1):                             # b_k = G_k + 2 L^T b_{k+1} - b_{k+2}, one launch each
+                t = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0, z2=G[k], gamma=1.0)
                 b1, b2 = t, b1
-            gx = csr_hop(opT, b1, z=b2, alpha=1.0, beta=-1.0)
-            gx.add_(G[0])
+            gx = csr_hop(opT, b1, z=b2, alpha=1.0, beta=-1.0, z2=G[0], gamma=1.0)   # dx = G_0 + L^T b_1 - b_2
     if bias_shape is not None and needs[2]:
         gb = g.sum(dim=(0, 1)) if bias_kind == BIAS_CHANNEL else g.sum(dim=0)
         gb = gb.reshape(bias_shape)
