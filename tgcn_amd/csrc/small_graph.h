@@ -566,11 +566,12 @@ inline int basis_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int* de
 constexpr int kDenseMaxN = 256;      // vertices (16 row tiles -> 16 waves)
 constexpr int kDenseMaxC = 32;       // input row length (X fragments in registers)
 constexpr int kDenseWFloats = 4096;  // LDS for weight tiles: all K of them when they fit (staged once), else one per step
-template <int S, bool BASIS, int NW>   // NW: most waves (16-row tiles) of a workgroup -> register budget and size of Lf
+// NW: most waves (16-row tiles) of a workgroup -> register budget and size of Lf; XKMAX: k-steps of the input row (C <= 4 XKMAX)
+template <int S, bool BASIS, int NW, int XKMAX>
 __global__ __launch_bounds__(NW * 64) void small_dense_kernel(const SmallParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int LDY = S * 16 + 16;
-  constexpr int NKMAX = NW * 4, XKMAX = kDenseMaxC / 4;
+  constexpr int NKMAX = NW * 4;
   constexpr int kDenseKB = 8 / S;                        // k-steps of B fragments per batch (8 LDS reads in flight)
   const int n = p.n, C = p.C;
   const int npad = (n + 15) / 16 * 16, nk = npad / 4;
@@ -735,7 +736,7 @@ inline int dense_mfma_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, in
   const int npad = (int)(n + 15) / 16 * 16;
   const int nbuf = mode == 0 ? 2 : 3;
   const int nw = npad / 16;            // register budget per lane shrinks with the wave count: fewer samples (accumulators)
-  const int smax = basis ? (nw > 12 ? 2 : 4) : (nw > 12 ? 1 : (nw > 8 ? 2 : 4));
+  const int smax = basis ? (nw > 12 ? 2 : 4) : (nw > 12 ? 1 : (nw > 10 ? 2 : 4));
   for (int S = smax; S >= 1; S /= 2) {
     const size_t fl = (size_t)(basis ? 0 : kDenseWFloats) + (size_t)nbuf * npad * (S * 16 + 16);
     if (fl * sizeof(float) > 160 * 1024) continue;
@@ -752,15 +753,20 @@ inline void launch_small_dense(hipStream_t st, const SmallParams& p, int S, int6
   const size_t lds = ((size_t)(BASIS ? 0 : kDenseWFloats) + (size_t)nbuf * npad * (S * 16 + 16)) * sizeof(float);
   const dim3 grid((unsigned)((p.q + S - 1) / S), (unsigned)col_tiles);
   const dim3 block((unsigned)(npad / 16 * 64));
-#define TGCN_DENSE(SV, NWV)                                                                  \
-  {                                                                                          \
-    allow_large_lds((const void*)small_dense_kernel<SV, BASIS, NWV>, 160 * 1024);            \
-    hipLaunchKernelGGL((small_dense_kernel<SV, BASIS, NWV>), grid, block, lds, st, p);       \
+#define TGCN_DENSE(SV, NWV, XKV)                                                                   \
+  {                                                                                                \
+    allow_large_lds((const void*)small_dense_kernel<SV, BASIS, NWV, XKV>, 160 * 1024);             \
+    hipLaunchKernelGGL((small_dense_kernel<SV, BASIS, NWV, XKV>), grid, block, lds, st, p);        \
   }
+#define TGCN_DENSE_X(SV, NWV) \
+  if (BASIS || p.C <= 16) TGCN_DENSE(SV, NWV, 4) else TGCN_DENSE(SV, NWV, kDenseMaxC / 4)
 #define TGCN_DENSE_S(NWV) \
-  if (S == 4) TGCN_DENSE(4, NWV) else if (S == 2) TGCN_DENSE(2, NWV) else TGCN_DENSE(1, NWV)
+  if (S == 4) { TGCN_DENSE_X(4, NWV) } else if (S == 2) { TGCN_DENSE_X(2, NWV) } else { TGCN_DENSE_X(1, NWV) }
   const int nw = npad / 16;
-  if (nw <= 8) { TGCN_DENSE_S(8) } else if (nw <= 12) { TGCN_DENSE_S(12) } else { TGCN_DENSE_S(16) }
+  // 9-10 waves: the forward kernel gets its own register budget (4 samples per workgroup fit); the basis kernel measured
+  // faster under the 12-wave bound
+  if (nw <= 8) { TGCN_DENSE_S(8) } else if (nw <= 10 && !BASIS) { TGCN_DENSE_S(10) } else if (nw <= 12) { TGCN_DENSE_S(12) } else { TGCN_DENSE_S(16) }
 #undef TGCN_DENSE_S
+#undef TGCN_DENSE_X
 #undef TGCN_DENSE
 }
