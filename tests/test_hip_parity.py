@@ -610,3 +610,32 @@ def test_cpu_tensor_fails_loudly():
     layer = tgcn_amd.GCNCheb(torch.eye(4), 1, 2, 2)
     with pytest.raises(TgcnError):
         layer(torch.randn(2, 4))
+
+
+def test_operand_cache_does_not_go_stale(gpu_device):
+    """A fresh edge_index per batch (same shape, new content) is usually handed the address the previous one just freed;
+    identity / data_ptr / version alone would then find the previous batch's operand.  Also: L replaced on a dense-L layer."""
+    import tgcn_amd
+    rng = np.random.default_rng(7)
+    n, E = 300, 2000
+    torch.manual_seed(0)
+    layer = tgcn_amd.ChebConv(2, 5, 4).cuda()
+    x = rng.standard_normal((2, n, 2)).astype(np.float32)
+    xt = _dev(x)
+    W, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+    for it in range(6):
+        ei = rng.integers(0, n, (2, E)).astype(np.int64)
+        ei_dev = _dev(ei)
+        out = layer(xt, ei_dev)
+        ref = O.cheb_conv_forward(x, ei, None, W, b)
+        assert rel_err(out.detach().cpu().numpy(), ref) <= TOL, it
+        del ei_dev, out                                   # frees the index tensor: its address is up for reuse
+    dl = tgcn_amd.GCNCheb(torch.eye(n), 2, 5, 3).cuda()
+    Wd, bd = dl.weight.detach().cpu().numpy(), dl.bias.detach().cpu().numpy()
+    for it in range(4):
+        Lnp = (rng.standard_normal((n, n)) * (rng.random((n, n)) < 0.02)).astype(np.float32)
+        dl.L = torch.tensor(Lnp)                          # the previous L dies here
+        out = dl(xt)
+        import scipy.sparse as sp
+        ref = O.gcn_cheb_forward(sp.csr_matrix(Lnp), x, Wd, bd)
+        assert rel_err(out.detach().cpu().numpy(), ref) <= TOL, it

@@ -33,18 +33,20 @@ def gcn_pool_4(x):
 
 class _OperandCache:
     """One GraphOperand per (source object identity, version, device): DataParallel replicas on other devices
-    and in-place edits of L / edge_index get their own."""
+    and in-place edits of L / edge_index get their own.  An entry keeps its source objects alive: identity and
+    data_ptr only name a tensor while it exists -- once freed, the allocator may hand the same address (and Python the
+    same id) to a new edge_index of the same shape, which must not find the old operand."""
 
     def __init__(self):
         self._d = {}
 
-    def get(self, key, build):
-        op = self._d.get(key)
-        if op is None:
+    def get(self, key, build, sources=()):
+        hit = self._d.get(key)
+        if hit is None:
             if len(self._d) > 16:
                 self._d.clear()
-            op = self._d[key] = build()
-        return op
+            hit = self._d[key] = (build(), tuple(sources))
+        return hit[0]
 
 
 def _tensor_key(t):
@@ -59,7 +61,7 @@ class _DenseLBase(torch.nn.Module):
         dense = isinstance(L, torch.Tensor) and L.layout == torch.strided
         key = (id(L), L.data_ptr() if dense else None, getattr(L, "_version", 0), tuple(L.shape) if hasattr(L, "shape") else None,
                str(device))
-        return self._ops.get(key, lambda: GraphOperand.from_any(L, device))
+        return self._ops.get(key, lambda: GraphOperand.from_any(L, device), sources=(L,))
 
     def _num_vertices(self):
         return self.L.shape[0] if hasattr(self.L, "shape") else self.L[0].shape[0]
@@ -193,7 +195,7 @@ _spmm_ops = _OperandCache()
 
 def _coo_operand(index, value, m, device):
     key = (_tensor_key(index), _tensor_key(value), int(m), str(device))
-    return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value, device))
+    return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value, device), sources=(index, value))
 
 
 def spmm(index, value, m, matrix):
@@ -226,7 +228,8 @@ class _EdgeBase(torch.nn.Module):
         if edge_weight is not None:
             assert edge_weight.reshape(-1).size(0) == edge_index.size(1)
         key = (_tensor_key(edge_index), _tensor_key(edge_weight), n, str(x.device))
-        return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, edge_weight, n, x.device))
+        return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, edge_weight, n, x.device),
+                             sources=(edge_index, edge_weight))
 
     def reset_parameters(self):
         size = self.in_channels * self.weight.size(0)
