@@ -49,6 +49,13 @@ class _OperandCache:
         return hit[0]
 
 
+def _np_fingerprint(L):
+    """scipy / ndarray operands carry no version counter: tag the first and last stored values so that an in-place
+    edit is (very likely) noticed."""
+    from .numpy_api import _fingerprint
+    return _fingerprint(L)
+
+
 def _tensor_key(t):
     return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
 
@@ -60,7 +67,7 @@ class _DenseLBase(torch.nn.Module):
         L = self.L
         dense = isinstance(L, torch.Tensor) and L.layout == torch.strided
         key = (id(L), L.data_ptr() if dense else None, getattr(L, "_version", 0), tuple(L.shape) if hasattr(L, "shape") else None,
-               str(device))
+               str(device), None if isinstance(L, torch.Tensor) else _np_fingerprint(L))
         return self._ops.get(key, lambda: GraphOperand.from_any(L, device), sources=(L,))
 
     def _num_vertices(self):

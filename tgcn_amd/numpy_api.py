@@ -9,6 +9,18 @@ from .graph import GraphOperand
 _cache = {}
 
 
+def _fingerprint(L):
+    """Cheap content tag so that in-place edits of a scipy / ndarray operand are (very likely) noticed: the callers
+    rebuild or rescale L between calls (examples/gcn_mnist.py:131)."""
+    data = getattr(L, "data", None)
+    if isinstance(data, np.ndarray) and data.size:
+        return (data.ctypes.data, data[:32].tobytes(), data[-32:].tobytes())
+    if isinstance(L, np.ndarray) and L.size:
+        flat = L.reshape(-1)
+        return (L.ctypes.data, flat[:32].tobytes(), flat[-32:].tobytes())
+    return None
+
+
 def chebyshev(L, X, K, device="cuda"):
     """2-D X (M, N): Xt[0]=X, Xt[1]=L X, Xt[k]=2 L^k X - Xt[k-2]  (graph.py:256-265); returns (K, M, N) in L.dtype.
     Arithmetic is fp32 on the device (the reference computes in L.dtype; fp64 operands are rounded to fp32).
@@ -16,12 +28,13 @@ def chebyshev(L, X, K, device="cuda"):
     that branch is reproduced literally (true recurrence on the reshaped matrix) because callers depend on it."""
     X = getattr(X, "_value", X)          # autograd boxes are unwrapped like graph.py:249-252
     X = np.asarray(X)
-    key = (id(L), getattr(L, "nnz", None), str(device))
-    op = _cache.get(key)
-    if op is None:
+    key = (id(L), getattr(L, "nnz", None), _fingerprint(L), str(device))
+    hit = _cache.get(key)
+    if hit is None:
         if len(_cache) > 8:
             _cache.clear()
-        op = _cache[key] = GraphOperand.from_any(L, device)
+        hit = _cache[key] = (GraphOperand.from_any(L, device), L)     # L kept alive: a freed object's id can come back
+    op = hit[0]
     out_dtype = L.dtype if hasattr(L, "dtype") else X.dtype
     if X.ndim == 2:
         x3 = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32), device=device).unsqueeze(0)
