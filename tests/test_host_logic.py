@@ -212,3 +212,22 @@ def test_compat_import_paths():
             "from tgcn.nn.gcn_matmul import GCNCheb as G2; from gcn.graph import chebyshev; import tgcn_amd; assert G2 is tgcn_amd.GCNCheb"
             % (ROOT, os.path.join(ROOT, "compat")))
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_modules_survive_deepcopy_and_pickle():
+    """copy.deepcopy(model) (best-model snapshots, EMA) and torch.save(model) must not trip over the operand cache."""
+    import copy
+    import io
+    import pickle
+    import tgcn_amd
+    L = torch.eye(12)
+    layer = tgcn_amd.TGCNCheb_H(L, 1, 4, 3, 5)
+    layer._ops.get(("k",), lambda: object(), sources=(L,))          # something unpicklable-ish in the cache
+    twin = copy.deepcopy(layer)
+    assert torch.equal(twin.weight, layer.weight) and twin._ops._d == {}
+    buf = io.BytesIO()
+    pickle.dump(layer, buf)
+    back = pickle.loads(buf.getvalue())
+    assert torch.equal(back.weight, layer.weight) and back._ops._d == {}
+    conv = copy.deepcopy(tgcn_amd.ChebConv(2, 3, 4))
+    assert conv.weight.shape == (4, 2, 3)

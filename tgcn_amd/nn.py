@@ -40,6 +40,16 @@ class _OperandCache:
     def __init__(self):
         self._d = {}
 
+    # copies and pickles of a module start with an empty cache (entries hold device pointers in ctypes structs)
+    def __deepcopy__(self, memo):
+        return _OperandCache()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self._d = {}
+
     def get(self, key, build, sources=()):
         hit = self._d.get(key)
         if hit is None:
