@@ -679,3 +679,26 @@ def test_backward_large_sparse_vs_scipy(mode, gpu_device):
         stack_k = O.stack_reference_power(LT, Gk, k + 1) if mode == 0 else O.stack_chebyshev(LT, Gk, k + 1)
         ref_dx += stack_k[k]
     assert rel_err(xt.grad.cpu().numpy(), ref_dx) <= 2e-5
+
+
+def test_hop_rectangular_operand(gpu_device):
+    """Vertex-shard operands are rectangular (owned rows x owned + halo columns): the hop reads n_cols input rows and
+    writes n output rows (tgcn_amd/dist.py builds them with from_coo(..., n_cols=...))."""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    import scipy.sparse as sp
+    rng = np.random.default_rng(8)
+    n, ncols, C = 700, 2500, 24
+    m = 9000
+    row = np.concatenate([rng.integers(0, n, m), np.full(900, 13)])
+    col = np.concatenate([rng.integers(0, ncols, m), rng.integers(0, ncols, 900)])
+    val = rng.standard_normal(row.shape[0]).astype(np.float32)
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val), n_cols=ncols)
+    assert op.n == n and op.n_cols == ncols
+    L = sp.coo_matrix((val.astype(np.float64), (row, col)), shape=(n, ncols)).tocsr()
+    x = rng.standard_normal((3, ncols, C)).astype(np.float32)
+    z = rng.standard_normal((3, n, C)).astype(np.float32)
+    y = F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0)
+    ref = np.stack([2.0 * L.dot(x[b].astype(np.float64)) - z[b] for b in range(3)])
+    assert y.shape == (3, n, C)
+    assert rel_err(y.cpu().numpy(), ref) <= TOL
