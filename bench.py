@@ -27,6 +27,14 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+def baseline_metric():
+    """The metric string of BASELINE.json, verbatim (the file travels with the repo)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except (OSError, KeyError, ValueError):
+        return "Cheb-TGCN fwd: G edge\u00b7timesteps/s + achieved HBM GB/s, K=5 on 160M-edge graph"
+
+
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
 
 
@@ -117,7 +125,7 @@ def cpu_baseline(op, spec, layer, x, budget_q=1):
     out = c_port.forward(0, rowptr, col, val, xs, W, b, kind)
     dt = time.perf_counter() - t0
     units = op.nnz * (K - 1) * q * spec["H"]
-    return out, dict(value=units / dt / 1e9, unit="G edge.timesteps/s", cores=c_port.threads(), kind="port",
+    return out, dict(value=units / dt / 1e9, unit="G edge\u00b7timesteps/s", cores=c_port.threads(), kind="port",
                      sample="%d of %d samples of the same workload, full K=%d forward, oracle/cheb_ref.c OpenMP, %.1f s" % (q, spec["q"], K, dt))
 
 
@@ -274,8 +282,7 @@ def main():
         assert err <= 1e-5, "GPU result differs from the CPU restatement: %g" % err
 
     if rank == 0:
-        line = dict(metric="Cheb-TGCN fwd: G edge.timesteps/s + achieved HBM GB/s, K=5 on 160M-edge graph",
-                    value=round(value, 3), unit="G edge.timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+        line = dict(metric=baseline_metric(), value=round(value, 3), unit="G edge\u00b7timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if (vertex_mode and ngroups == 1) else "weak", vs_baseline=None,
                     dtype="f32", data="synthetic",
                     config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
