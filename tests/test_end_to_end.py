@@ -71,3 +71,75 @@ def test_two_layer_model_trains(gpu_device):
     net2.load_state_dict(net.state_dict())
     with torch.no_grad():
         assert torch.equal(net(x), net2(x))
+
+
+def test_training_step_is_hipgraph_capturable(gpu_device):
+    """Forward + backward + SGD of a two-layer model captured into ONE hipGraph (torch.cuda.graphs) and replayed on new
+    batches: same losses as the eager loop.  Small-batch steps are bound by the host (autograd engine, ~0.2 ms); a
+    captured step issues in a few microseconds."""
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    try:
+        from tgcn.nn.gcn import GCNCheb, TGCNCheb_H, gcn_pool_4
+    finally:
+        sys.path.pop(0)
+    rng = np.random.default_rng(1)
+    L0, L2 = _ring_graph(160, 30, rng), _ring_graph(40, 8, rng)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.tgcn1 = TGCNCheb_H(L0, 1, 16, 6, 15)
+            self.gcn2 = GCNCheb(L2, 16, 24, 5)
+            self.fc = nn.Linear(10 * 24, 6)
+
+        def forward(self, x):
+            x = gcn_pool_4(TF.relu(self.tgcn1(x)))
+            x = gcn_pool_4(TF.relu(self.gcn2(x)))
+            return TF.log_softmax(self.fc(x.view(x.shape[0], -1)), dim=1)
+
+    def make():
+        torch.manual_seed(3)
+        net = Net().cuda()
+        return net, torch.optim.SGD(net.parameters(), lr=0.05)
+
+    batches = [(torch.randn(32, 160, 15, device="cuda"), torch.randint(0, 6, (32,), device="cuda")) for _ in range(5)]
+    # eager reference
+    net, opt = make()
+    eager = []
+    for x, y in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = TF.nll_loss(net(x), y)
+        loss.backward()
+        opt.step()
+        eager.append(float(loss.detach()))
+    # captured: warm-up steps on a side stream (the documented torch.cuda.graphs recipe), then capture one step
+    net, opt = make()
+    xs, ys = batches[0][0].clone(), batches[0][1].clone()
+    snapshot = [p.detach().clone() for p in net.parameters()]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            TF.nll_loss(net(xs), ys).backward()
+            opt.step()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.no_grad():
+        for p, p0 in zip(net.parameters(), snapshot):      # undo the warm-up updates
+            p.copy_(p0)
+    g = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        loss_static = TF.nll_loss(net(xs), ys)
+        loss_static.backward()
+        opt.step()
+    with torch.no_grad():
+        for p, p0 in zip(net.parameters(), snapshot):      # the capture itself does not run, but be explicit
+            p.copy_(p0)
+    got = []
+    for x, y in batches:
+        xs.copy_(x)
+        ys.copy_(y)
+        g.replay()
+        got.append(float(loss_static.detach()))
+    assert np.allclose(got, eager, rtol=2e-4, atol=1e-5), (got, eager)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--fused", action="store_true", help="use tgcn_amd.cheb_relu_pool for layer + relu + pool")
+    ap.add_argument("--graph", action="store_true", help="capture the training step into one hipGraph (torch.cuda.graphs) and replay it")
     args = ap.parse_args()
     from tgcn.nn.gcn import GCNCheb, TGCNCheb_H, gcn_pool_4           # the reference's import line
     import tgcn_amd
@@ -72,14 +73,36 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(10):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    if args.graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(5):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            loss = TF.nll_loss(net(x), y)
+            loss.backward()
+            opt.step()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+    else:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
     with torch.no_grad():
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -87,7 +110,8 @@ def main():
         torch.cuda.synchronize()
         df = (time.perf_counter() - t0) / args.steps
     print("HCP-style model, batch %d, %s: inference %.3f ms, training step %.3f ms (%.0f samples/s), loss %.4f" % (
-        args.batch, "fused relu+pool" if args.fused else "plain modules", df * 1e3, dt * 1e3, args.batch / dt, float(loss)), flush=True)
+        args.batch, ("fused relu+pool" if args.fused else "plain modules") + (", step replayed from a hipGraph" if args.graph else ""),
+        df * 1e3, dt * 1e3, args.batch / dt, float(loss.detach())), flush=True)
 
 
 if __name__ == "__main__":
