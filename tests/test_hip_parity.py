@@ -342,7 +342,8 @@ def test_small_basis_kernel_vs_oracle(n, q, C, K, gpu_device):
             assert rel_err(terms[k].cpu().numpy(), ref[k]) <= TOL, (mode, k)
 
 
-@pytest.mark.parametrize("n,q,Crow,N,K", [(148, 9, 15, 32, 10), (200, 5, 32, 40, 4), (256, 3, 8, 16, 5), (40, 700, 5, 7, 3), (100, 2, 1, 64, 2), (130, 3, 4, 4, 1)])
+@pytest.mark.parametrize("n,q,Crow,N,K", [(148, 9, 15, 32, 10), (200, 5, 32, 40, 4), (256, 3, 8, 16, 5), (40, 700, 5, 7, 3), (100, 2, 1, 64, 2), (130, 3, 4, 4, 1),
+                                          (40, 70, 64, 32, 10), (128, 3, 48, 16, 3)])
 def test_small_dense_operand_on_matrix_pipe(n, q, Crow, N, K, gpu_device):
     """Dense small operands (>= 1/4 of the entries stored, n <= 256, C <= 32) run the one-launch layer and the basis on
     the fp32 MFMA: against the oracle, both modes, all bias kinds, in-kernel fold, and against the vector-ALU kernels."""

@@ -564,7 +564,8 @@ inline int basis_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int* de
 // k rows of a B-fragment read fall into different banks).  v_mfma_f32_16x16x4_f32: k-ordered fp32 fmaf chain.
 //   A lane (r = lane&15, kq = lane>>4) = A[row r][k kq];  B = B[k kq][col r];  D[i] = D[row 4*kq+i][col r].
 constexpr int kDenseMaxN = 256;      // vertices (16 row tiles -> 16 waves)
-constexpr int kDenseMaxC = 32;       // input row length (X fragments in registers)
+constexpr int kDenseMaxC = 32;       // input row length (X fragments in registers) ...
+constexpr int kDenseMaxCSmall = 64;  // ... 64 for operands of up to 128 vertices (8 waves: 256 registers per lane)
 constexpr int kDenseWFloats = 4096;  // LDS for weight tiles: all K of them when they fit (staged once), else one per step
 // NW: most waves (16-row tiles) of a workgroup -> register budget and size of Lf; XKMAX: k-steps of the input row (C <= 4 XKMAX)
 template <int S, bool BASIS, int NW, int XKMAX>
@@ -731,7 +732,8 @@ __global__ __launch_bounds__(NW * 64) void small_dense_kernel(const SmallParams 
 
 // samples per workgroup (4 / 2 / 1) of small_dense_kernel, 0 when the shape is not for it
 inline int dense_mfma_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int64_t q, int64_t col_tiles, bool basis) {
-  if (n < 16 || n > kDenseMaxN || (!basis && C > kDenseMaxC) || (mode != 0 && mode != 1)) return 0;
+  if (n < 16 || n > kDenseMaxN || (mode != 0 && mode != 1)) return 0;
+  if (!basis && C > (n <= 128 ? kDenseMaxCSmall : kDenseMaxC)) return 0;
   if (nnz * 4 < n * n) return 0;                       // at least a quarter of the entries stored: dense arithmetic pays
   const int npad = (int)(n + 15) / 16 * 16;
   const int nbuf = mode == 0 ? 2 : 3;
@@ -758,8 +760,10 @@ inline void launch_small_dense(hipStream_t st, const SmallParams& p, int S, int6
     allow_large_lds((const void*)small_dense_kernel<SV, BASIS, NWV, XKV>, 160 * 1024);             \
     hipLaunchKernelGGL((small_dense_kernel<SV, BASIS, NWV, XKV>), grid, block, lds, st, p);        \
   }
-#define TGCN_DENSE_X(SV, NWV) \
-  if (BASIS || p.C <= 16) TGCN_DENSE(SV, NWV, 4) else TGCN_DENSE(SV, NWV, kDenseMaxC / 4)
+#define TGCN_DENSE_X(SV, NWV)                                                      \
+  if (BASIS || p.C <= 16) TGCN_DENSE(SV, NWV, 4)                                   \
+  else if (p.C <= kDenseMaxC) TGCN_DENSE(SV, NWV, kDenseMaxC / 4)                  \
+  else if constexpr (NWV == 8) TGCN_DENSE(SV, NWV, kDenseMaxCSmall / 4)
 #define TGCN_DENSE_S(NWV) \
   if (S == 4) { TGCN_DENSE_X(4, NWV) } else if (S == 2) { TGCN_DENSE_X(2, NWV) } else { TGCN_DENSE_X(1, NWV) }
   const int nw = npad / 16;

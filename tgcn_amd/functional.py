@@ -402,7 +402,7 @@ class ChebReluPoolFn(torch.autograd.Function):
         L = _lib.lib()
         # dense small operands run the layer on the matrix pipe (no fused epilogue there): layer + one relu/pool pass beats
         # the fused vector-ALU kernel (HCP shape: 136 + 15 us against 330 us)
-        dense_mfma = op.dense is not None and Crow <= 32
+        dense_mfma = op.dense is not None and (Crow <= 32 or (Crow <= 64 and op.n <= 128))
         if small_path_tile(op, Crow, mode, pool=True) and not dense_mfma:
             _lib.check(L.tgcn_cheb_forward_small_pool_f32(_lib.stream_ptr(), C.byref(op.struct), mode, K, q, Crow, N, _lib.ptr(x3),
                                                           _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
