@@ -105,7 +105,8 @@ int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* coun
  *                     4 exact-fp32 auto; 5 vector-ALU narrow kernel wherever it applies
  *   "x3_form"         2 (default) bf16x3 with A fragments from registers for >= 96 output columns; 1 both operands via LDS
  *   "overlap"         1: projection of pass i on a side stream under the hops of pass i+1 (default 0)
- *   "small_dense"     0: dense small operands stay on the vector-ALU one-launch kernels (default 1: matrix pipe)
+ *   "small_dense"     dense small operands: 2 (default) bf16x3 on the matrix pipe when the batch fills the chip, 1 exact
+ *                     fp32 MFMA only, 0 vector-ALU one-launch kernels
  *   "small_narrow"    0: C <= 4 inputs use the output-side one-launch kernel (default 1: input-side recursion) */
 int tgcn_set_tuning(const char* key, int32_t value);
 
@@ -191,7 +192,8 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
  * applied while the weight is staged so the caller passes the layer's raw weight.
  * tgcn_cheb_forward_small_supported returns the channel tile (16 / 8) or 0 when the shape does not fit.
  * Operands that store at least a quarter of their entries (n <= 256, C <= 32: the 148-parcel DTI graph of load/res) run
- * the same recursion on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), L held as A-fragments in registers;
+ * the same recursion on the matrix pipe, L held as A-fragments in registers: exact fp32 (v_mfma_f32_16x16x4_f32), or -- when
+ * the batch fills the chip -- the three-way bf16 split of the projection kernels (fp32-accurate, 2.7x fewer MFMA cycles);
  * tgcn_set_tuning("small_dense", 0) keeps them on the vector-ALU kernel. */
 int tgcn_cheb_forward_small_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode);   /* counts on A->dense for dense operands */
 int tgcn_cheb_forward_small_pool_supported(int64_t n, int64_t nnz, int32_t C, int32_t mode);   /* ... with the fused relu + pool epilogue */

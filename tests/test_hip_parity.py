@@ -343,10 +343,12 @@ def test_small_basis_kernel_vs_oracle(n, q, C, K, gpu_device):
 
 
 @pytest.mark.parametrize("n,q,Crow,N,K", [(148, 9, 15, 32, 10), (200, 5, 32, 40, 4), (256, 3, 8, 16, 5), (40, 700, 5, 7, 3), (100, 2, 1, 64, 2), (130, 3, 4, 4, 1),
-                                          (40, 70, 64, 32, 10), (128, 3, 48, 16, 3)])
+                                          (40, 70, 64, 32, 10), (128, 3, 48, 16, 3), (148, 300, 15, 32, 10), (40, 800, 32, 16, 5), (64, 500, 40, 48, 3)])
 def test_small_dense_operand_on_matrix_pipe(n, q, Crow, N, K, gpu_device):
-    """Dense small operands (>= 1/4 of the entries stored, n <= 256, C <= 32) run the one-launch layer and the basis on
-    the fp32 MFMA: against the oracle, both modes, all bias kinds, in-kernel fold, and against the vector-ALU kernels."""
+    """Dense small operands (>= 1/4 of the entries stored, n <= 256, C <= 32, or C <= 64 up to 128 vertices) run the
+    one-launch layer and the basis on the matrix pipe -- bf16x3 when the batch fills the chip (the q >= 300 cases), exact
+    fp32 MFMA otherwise: against the oracle, both modes, all bias kinds, in-kernel fold, and against the vector-ALU
+    kernels."""
     from tgcn_amd import functional as F, _lib
     from tgcn_amd.graph import GraphOperand
     rng = np.random.default_rng(n + K)
@@ -372,7 +374,7 @@ def test_small_dense_operand_on_matrix_pipe(n, q, Crow, N, K, gpu_device):
             try:
                 out_valu = F.cheb_forward_small(*args) if F.small_path_tile(op, Crow, mode) else None   # n > ~190 does not fit it
             finally:
-                _lib.check(_lib.lib().tgcn_set_tuning(b"small_dense", 1))
+                _lib.check(_lib.lib().tgcn_set_tuning(b"small_dense", 2))
             assert out_valu is None or rel_err(out.cpu().numpy(), out_valu.cpu().numpy()) <= TOL
     for mode in (F.MODE_POWER, F.MODE_CHEBYSHEV):
         if mode == F.MODE_POWER:

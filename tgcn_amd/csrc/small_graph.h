@@ -730,6 +730,200 @@ __global__ __launch_bounds__(NW * 64) void small_dense_kernel(const SmallParams 
   }
 }
 
+// ---- the same dense recursion with L . Y on the bf16 matrix pipe, fp32-accurate through the three-way split of project.h
+// (a = a1 + a2 + a3 exactly, six v_mfma_f32_16x16x32_bf16 per 32 k instead of eight fp32 MFMAs of twice the cycles).
+// L is split once: a wave keeps the three planes of its 16 x npad strip in registers (12 per 32 k).  Y lives in LDS
+// TRANSPOSED and already split -- YT[plane][column (S*16)][k = vertex] in bf16 -- so that a B fragment (8 consecutive
+// k of one column) is one ds_read_b128 and a wave's result (4 consecutive vertices of one column per lane) is one
+// ds_write_b64 per plane; rows are padded by 8 elements so that the 16 columns of a read fall on different banks.
+// The fp32 value of a previous step (Clenshaw's b_{k+2}) is the exact sum of its three planes.  X W_j stays on the fp32
+// MFMA (a small part of the work).
+template <int S, bool BASIS, int NW, int XKMAX>
+__global__ __launch_bounds__(NW * 64) void small_dense_x3_kernel(const SmallParams p) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int NKT = NW / 2 + (NW & 1);                 // 32-k tiles of L (npad <= 16 NW)
+  const int n = p.n, C = p.C;
+  const int npad = (n + 15) / 16 * 16;
+  const int kpad = (npad + 31) / 32 * 32, nkt = kpad / 32;
+  const int ldk = kpad + 8;                              // bf16 elements per YT row
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int i0 = wave * 16;
+  const int nbuf = p.mode == 0 ? 2 : 3;
+  const int cpad = (C + 3) / 4 * 4, xk = cpad / 4;
+  float* Wt = smem;
+  unsigned short* Yb = reinterpret_cast<unsigned short*>(smem + (BASIS ? 0 : kDenseWFloats));   // nbuf x [3][S*16][ldk]
+  const int plane = S * 16 * ldk, buf = 3 * plane;
+  const bool w_all = !BASIS && p.K * cpad * 16 <= kDenseWFloats;
+  const int q0 = blockIdx.x * S, n0 = blockIdx.y * 16;
+
+  // ---- L planes: lane (r, kq) holds L[i0 + r][32 t + 8 kq + j], j = 0..7, split three ways
+  bf16x8 La[NKT][3];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = i0 + r, col = t * 32 + kq * 8 + j;
+      v[j] = (t < nkt && row < n && col < n) ? p.Ld[(int64_t)row * n + col] : 0.f;
+    }
+    unsigned pl[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(v[2 * j], v[2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
+#pragma unroll
+    for (int q3 = 0; q3 < 3; ++q3) {
+      using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+      La[t][q3] = __builtin_bit_cast(bf16x8, u32x4{pl[q3][0], pl[q3][1], pl[q3][2], pl[q3][3]});
+    }
+  }
+  // zero every Y buffer once: k padding (vertices >= npad) must read as zero
+  for (int e = tid; e < nbuf * buf / 2; e += nthr) reinterpret_cast<unsigned*>(Yb)[e] = 0u;
+  float Xf[BASIS ? 1 : S][BASIS ? 1 : XKMAX];
+  if constexpr (!BASIS) {
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int kt = 0; kt < XKMAX; ++kt) {
+        const int c = kt * 4 + kq, i = i0 + r;
+        Xf[s][kt] = (q0 + s < p.q && i < n && c < C) ? p.x[((int64_t)(q0 + s) * n + i) * C + c] : 0.f;
+      }
+  }
+  __syncthreads();
+  // write 4 consecutive vertices (i4 .. i4+3) of column sc into buffer b, split into the three planes
+  auto put4 = [&](int b, int sc, int i4, float v0, float v1, float v2, float v3) {
+    unsigned a1, a2, a3, b1, b2, b3;
+    split3(v0, v1, a1, a2, a3);
+    split3(v2, v3, b1, b2, b3);
+    unsigned short* d = Yb + b * buf + sc * ldk + i4;
+    *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(d + plane) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2(a3, b3);
+  };
+  auto bf2f = [](unsigned short h) { return __uint_as_float((unsigned)h << 16); };
+  if constexpr (BASIS) {                                  // buffer 0 = x tile
+    for (int e = tid; e < (npad / 4) * S * 16; e += nthr) {
+      const int sc = e % (S * 16), i4 = (e / (S * 16)) * 4, s = sc >> 4, c = n0 + (sc & 15);
+      float v[4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+        v[ii] = (q0 + s < p.q && i4 + ii < n && c < C) ? p.x[((int64_t)(q0 + s) * n + i4 + ii) * C + c] : 0.f;
+      put4(0, sc, i4, v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+  }
+  auto stage_w = [&](float* dst, int j) {
+    for (int e = tid; e < cpad * 16; e += nthr) {
+      const int c = e >> 4, g = e & 15;
+      float w = 0.f;
+      if (c < C && n0 + g < p.N) {
+        if (p.fold) w = folded_weight(p.fold, p.W, p.K, j, (int64_t)C * p.N, (int64_t)c * p.N + n0 + g);
+        else w = p.W[((int64_t)j * C + c) * p.N + n0 + g];
+      }
+      dst[e] = w;
+    }
+  };
+  if constexpr (!BASIS) {
+    if (w_all) {
+      for (int j = 0; j < p.K; ++j) stage_w(Wt + j * cpad * 16, j);
+      __syncthreads();
+    }
+  }
+  int cur = BASIS ? 1 : 0;
+  const int nsteps = BASIS ? p.K - 1 : p.K;
+  for (int st = 0; st < nsteps; ++st) {
+    const int j = BASIS ? st + 1 : p.K - 1 - st;
+    if constexpr (!BASIS) {
+      if (!w_all) {
+        stage_w(Wt, j);
+        __syncthreads();
+      }
+    }
+    const float* Wj = w_all ? Wt + j * cpad * 16 : Wt;
+    const bool first = !BASIS && st == 0;
+    const float alpha = BASIS ? ((p.mode == 1 && j >= 2) ? 2.f : 1.f) : ((p.mode == 1 && j > 0) ? 2.f : 1.f);
+    const bool sub = p.mode == 1 && (BASIS ? j >= 2 : j <= p.K - 3);
+    const int b1 = (cur + nbuf - 1) % nbuf, b2 = (cur + nbuf - 2) % nbuf;
+    f32x4 acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+      const unsigned short* Y1 = Yb + b1 * buf + r * ldk + kq * 8;     // + s*16*ldk + plane*q3 + 32 t
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        if (t < nkt) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            bf16x8 w[3];
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) w[q3] = *reinterpret_cast<const bf16x8*>(Y1 + s * 16 * ldk + q3 * plane + t * 32);
+            f32x4 c = acc[s];     // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(La[t][2], w[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(La[t][1], w[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(La[t][0], w[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(La[t][1], w[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(La[t][0], w[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(La[t][0], w[0], c, 0, 0, 0);
+            acc[s] = c;
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sub) {                                          // b_{k+2}: exact sum of its three planes
+          const unsigned short* d = Yb + b2 * buf + (s * 16 + r) * ldk + i0 + kq * 4;
+#pragma unroll
+          for (int q3 = 0; q3 < 3; ++q3) {
+            const uint2 h = *reinterpret_cast<const uint2*>(d + q3 * plane);
+            z[0] += bf2f((unsigned short)(h.x & 0xFFFF)); z[1] += bf2f((unsigned short)(h.x >> 16));
+            z[2] += bf2f((unsigned short)(h.y & 0xFFFF)); z[3] += bf2f((unsigned short)(h.y >> 16));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[s][i] = sub ? fmaf(alpha, acc[s][i], -z[i]) : alpha * acc[s][i];
+      }
+    }
+    if constexpr (!BASIS) {
+#pragma unroll
+      for (int kt = 0; kt < XKMAX; ++kt) {
+        if (kt < xk) {
+          const float wv = Wj[(kt * 4 + kq) * 16 + r];
+#pragma unroll
+          for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xf[s][kt], wv, acc[s], 0, 0, 0);
+        }
+      }
+    }
+    const bool last = st == nsteps - 1;
+    if (!last) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) put4(cur, s * 16 + r, i0 + kq * 4, acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+    }
+    if (BASIS || last) {
+      const int ch = n0 + r;
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i0 + kq * 4 + i;
+          if (q0 + s >= p.q || row >= n) continue;
+          if constexpr (BASIS) {
+            if (ch < C) p.out[(((int64_t)j * p.q + q0 + s) * n + row) * C + ch] = acc[s][i];
+          } else {
+            if (ch < p.N) {
+              float v = acc[s][i];
+              if (p.bias_kind == 1) v += p.bias[ch];
+              else if (p.bias_kind == 2) v += p.bias[(int64_t)row * p.N + ch];
+              p.out[((int64_t)(q0 + s) * n + row) * p.N + ch] = v;
+            }
+          }
+        }
+    }
+    __syncthreads();
+    cur = (cur + 1) % nbuf;
+  }
+}
+
 // samples per workgroup (4 / 2 / 1) of small_dense_kernel, 0 when the shape is not for it
 inline int dense_mfma_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int64_t q, int64_t col_tiles, bool basis) {
   if (n < 16 || n > kDenseMaxN || (mode != 0 && mode != 1)) return 0;
@@ -773,4 +967,47 @@ inline void launch_small_dense(hipStream_t st, const SmallParams& p, int S, int6
 #undef TGCN_DENSE_S
 #undef TGCN_DENSE_X
 #undef TGCN_DENSE
+}
+
+inline size_t dense_x3_lds_bytes(int n, int S, int mode, bool basis) {
+  const int npad = (n + 15) / 16 * 16, kpad = (npad + 31) / 32 * 32;
+  const size_t ybytes = (size_t)(mode == 0 ? 2 : 3) * 3 * S * 16 * (kpad + 8) * sizeof(unsigned short);
+  return (basis ? 0 : (size_t)kDenseWFloats * sizeof(float)) + ybytes;
+}
+
+// samples per workgroup (4 / 2) of small_dense_x3_kernel, 0: use the fp32 form
+inline int dense_x3_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int64_t q, int64_t col_tiles, bool basis) {
+  if (!dense_mfma_config(n, nnz, C, mode, q, col_tiles, basis)) return 0;
+  const int nw = ((int)n + 15) / 16;
+  if (nw > 12) return 0;                                     // 13-16 waves: 128 registers per lane do not hold the L planes
+  for (int S = (nw > 8 ? 2 : 4); S >= 2; S /= 2) {
+    if (dense_x3_lds_bytes((int)n, S, mode, basis) > 160 * 1024) continue;
+    if ((q + S - 1) / S * col_tiles < 192) continue;       // keep most CUs busy
+    return S;
+  }
+  return 0;
+}
+
+template <bool BASIS>
+inline void launch_small_dense_x3(hipStream_t st, const SmallParams& p, int S, int64_t col_tiles) {
+  const int npad = (p.n + 15) / 16 * 16;
+  const size_t lds = dense_x3_lds_bytes(p.n, S, p.mode, BASIS);
+  const dim3 grid((unsigned)((p.q + S - 1) / S), (unsigned)col_tiles);
+  const dim3 block((unsigned)(npad / 16 * 64));
+#define TGCN_DX3(SV, NWV, XKV)                                                                       \
+  {                                                                                                  \
+    allow_large_lds((const void*)small_dense_x3_kernel<SV, BASIS, NWV, XKV>, 160 * 1024);            \
+    hipLaunchKernelGGL((small_dense_x3_kernel<SV, BASIS, NWV, XKV>), grid, block, lds, st, p);       \
+  }
+#define TGCN_DX3_X(SV, NWV)                                                          \
+  if (BASIS || p.C <= 16) TGCN_DX3(SV, NWV, 4)                                       \
+  else if (p.C <= kDenseMaxC) TGCN_DX3(SV, NWV, kDenseMaxC / 4)                      \
+  else if constexpr (NWV == 8) TGCN_DX3(SV, NWV, kDenseMaxCSmall / 4)
+#define TGCN_DX3_S(NWV) \
+  if (S == 4) { TGCN_DX3_X(4, NWV) } else { TGCN_DX3_X(2, NWV) }
+  const int nw = npad / 16;
+  if (nw <= 8) { TGCN_DX3_S(8) } else if (nw <= 12) { TGCN_DX3_S(12) } else { TGCN_DX3_S(16) }
+#undef TGCN_DX3_S
+#undef TGCN_DX3_X
+#undef TGCN_DX3
 }

@@ -399,10 +399,12 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
     const int64_t tiles16 = (N + 15) / 16;
     const int S = dense_mfma_config(A->n, A->nnz, C, mode, q, tiles16, false);
     if (S && tiles16 <= 65535) {
-      p.npad = 0; p.spw = S;
       hipStream_t st = (hipStream_t)stream;
       ProfScope ps(TGCN_PROF_SMALL, st);
-      launch_small_dense<false>(st, p, S, tiles16);
+      const int S3 = g_small_dense.load() >= 2 ? dense_x3_config(A->n, A->nnz, C, mode, q, tiles16, false) : 0;
+      p.npad = 0; p.spw = S3 ? S3 : S;
+      if (S3) launch_small_dense_x3<false>(st, p, S3, tiles16);     // L . Y on the bf16 matrix pipe, three-way split
+      else launch_small_dense<false>(st, p, S, tiles16);
       TGCN_CHECK_LAUNCH("tgcn_cheb_forward_small_f32 (dense)");
       return TGCN_OK;
     }
@@ -487,10 +489,12 @@ int tgcn_cheb_basis_small_f32(void* stream, const tgcn_csr* A, int32_t mode, int
     const int64_t tiles16 = (C + 15) / 16;
     const int S = dense_mfma_config(A->n, A->nnz, C, mode, q, tiles16, true);
     if (S) {
-      p.spw = S;
       hipStream_t st = (hipStream_t)stream;
       ProfScope ps(TGCN_PROF_SMALL_BASIS, st);
-      launch_small_dense<true>(st, p, S, tiles16);
+      const int S3 = g_small_dense.load() >= 2 ? dense_x3_config(A->n, A->nnz, C, mode, q, tiles16, true) : 0;
+      p.spw = S3 ? S3 : S;
+      if (S3) launch_small_dense_x3<true>(st, p, S3, tiles16);
+      else launch_small_dense<true>(st, p, S, tiles16);
       TGCN_CHECK_LAUNCH("tgcn_cheb_basis_small_f32 (dense)");
       return TGCN_OK;
     }
