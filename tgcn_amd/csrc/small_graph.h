@@ -980,7 +980,7 @@ inline int dense_x3_config(int64_t n, int64_t nnz, int32_t C, int32_t mode, int6
   if (!dense_mfma_config(n, nnz, C, mode, q, col_tiles, basis)) return 0;
   const int nw = ((int)n + 15) / 16;
   if (nw > 12) return 0;                                     // 13-16 waves: 128 registers per lane do not hold the L planes
-  for (int S = (nw > 8 ? 2 : 4); S >= 2; S /= 2) {
+  for (int S = ((nw > 10 || (basis && nw > 8)) ? 2 : 4); S >= 2; S /= 2) {
     if (dense_x3_lds_bytes((int)n, S, mode, basis) > 160 * 1024) continue;
     if ((q + S - 1) / S * col_tiles < 192) continue;       // keep most CUs busy
     return S;
@@ -1006,7 +1006,7 @@ inline void launch_small_dense_x3(hipStream_t st, const SmallParams& p, int S, i
 #define TGCN_DX3_S(NWV) \
   if (S == 4) { TGCN_DX3_X(4, NWV) } else { TGCN_DX3_X(2, NWV) }
   const int nw = npad / 16;
-  if (nw <= 8) { TGCN_DX3_S(8) } else if (nw <= 12) { TGCN_DX3_S(12) } else { TGCN_DX3_S(16) }
+  if (nw <= 8) { TGCN_DX3_S(8) } else if (nw <= 10 && !BASIS) { TGCN_DX3_S(10) } else if (nw <= 12) { TGCN_DX3_S(12) } else { TGCN_DX3_S(16) }
 #undef TGCN_DX3_S
 #undef TGCN_DX3_X
 #undef TGCN_DX3
