@@ -281,6 +281,40 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
 
 
+def relayout_qnc_to_nqc(x3):
+    """(q, n, C) -> (n, q, C) contiguous: the LDS-tiled transpose kernel for C <= 32, torch otherwise."""
+    q, n, Crow = x3.shape
+    if Crow > 32 or q == 1:
+        return x3.permute(1, 0, 2).contiguous()
+    _lib.require_device(x3)
+    out = torch.empty((n, q, Crow), dtype=torch.float32, device=x3.device)
+    _lib.check(_lib.lib().tgcn_relayout_qnc_to_nqc_f32(_lib.stream_ptr(), _lib.ptr(x3.contiguous()), _lib.ptr(out), q, n, Crow))
+    return out
+
+
+KEEP_BASIS_BYTES = 2 << 30    # training on the hops-then-projection path keeps the hop tensors for the backward up to this size
+
+
+def forward_keeping_basis(op, x3, Wt, bias, bias_kind, mode):
+    """Hops-then-projection forward that hands the K hop tensors to the caller (they ARE the basis the weight gradient
+    needs: monomials L^k x for the folded weight, Chebyshev T_k x for mode 1), instead of recomputing them in backward.
+    Same kernels as tgcn_cheb_forward_f32, one call per hop.  -> (out (q, n, N), terms as (q*n, C) row views, row order)
+    row order "nq": rows are (vertex, sample) -- layout 1, one long row per vertex for the gathers -- else (sample, vertex)."""
+    q, n, Crow = x3.shape
+    K, _, N = Wt.shape
+    nq = choose_layout(q, n, Crow) == 1
+    x0 = relayout_qnc_to_nqc(x3).view(1, n, q * Crow) if nq else x3
+    terms = [x0]
+    for k in range(1, K):
+        if mode == MODE_POWER or k == 1:
+            terms.append(csr_hop(op, terms[k - 1]))
+        else:
+            terms.append(csr_hop(op, terms[k - 1], z=terms[k - 2], alpha=2.0, beta=-1.0))
+    rows = [t.reshape(q * n, Crow) for t in terms]
+    out = cheb_project(rows, Wt, bias, bias_kind, n, interleave=q if nq else 1).view(q, n, N)
+    return out, rows, nq
+
+
 class ChebLayerFn(torch.autograd.Function):
     """out = sum_k T_k x W_k + bias with T_k given by `mode`; x3 (q,n,C), W (K, C, N) in the REFERENCE basis.
     For MODE_POWER the weight is folded to the monomial basis (W'_j = sum_k c[k,j] W_k): inside the kernel on the
@@ -293,7 +327,14 @@ class ChebLayerFn(torch.autograd.Function):
         W = W.contiguous()
         b = bias.contiguous() if bias is not None else None
         fold = power_fold_matrix(K, W.device) if (mode == MODE_POWER and K > 2) else None
-        out = layer_forward(op, x3, W, fold, b, bias_kind, mode)
+        ctx.basis = None
+        general = not small_path_tile(op, Crow, mode) and not use_project_first(x3.shape[0], x3.shape[1], Crow, N)
+        if general and K > 1 and ctx.needs_input_grad[1] and K * x3.numel() * 4 <= KEEP_BASIS_BYTES:
+            Wt = torch.mm(fold.t(), W.reshape(K, Crow * N)).view(K, Crow, N) if fold is not None else W
+            out, rows, nq = forward_keeping_basis(op, x3, Wt, b, bias_kind, mode)
+            ctx.basis = (rows, nq)
+        else:
+            out = layer_forward(op, x3, W, fold, b, bias_kind, mode)
         ctx.save_for_backward(x3, W)
         ctx.op, ctx.mode, ctx.bias_kind, ctx.fold = op, mode, bias_kind, fold
         ctx.bias_shape = None if bias is None else bias.shape
@@ -302,7 +343,9 @@ class ChebLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x3, W = ctx.saved_tensors
-        gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad)
+        gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad,
+                                    basis=ctx.basis)
+        ctx.basis = None
         return gx, gW, gb, None, None, None
 
 
@@ -332,7 +375,7 @@ def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode):
     return ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind)
 
 
-def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs):
+def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis=None):
     """Gradients of the layer w.r.t. (x3, W, bias).  All contractions run in libtgcn_hip.so: the basis is recomputed
     with the hop kernel, dW is the MFMA weight-gradient kernel, G = g W^T is the projection kernel with the transposed
     weight, dx is Horner (mode 0) / Clenshaw (mode 1) on L^T with the hop kernel; only the bias reduction and the
@@ -346,7 +389,13 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs):
     g = g.contiguous()
     g2d = g.reshape(q * n, N)
     gx = gW = gb = None
-    if needs[1]:
+    if needs[1] and basis is not None:                                # hop tensors kept by the forward (forward_keeping_basis)
+        rows, nq = basis
+        g_rows = relayout_qnc_to_nqc(g).view(q * n, N) if nq else g2d     # same (vertex, sample) row order as the terms
+        gW = cheb_wgrad(rows, g_rows)
+        if fold is not None:
+            gW = torch.mm(fold, gW.view(K, Crow * N)).view(K, Crow, N)
+    elif needs[1]:
         x3c = x3.contiguous()
         if small_basis_tile(op, Crow, mode):                          # small graphs: the whole basis in one launch
             basis = cheb_basis_small(op, x3c, K, mode)
