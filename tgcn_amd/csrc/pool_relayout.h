@@ -5,12 +5,13 @@
 // --------------------------------------------------------------------------------------------------
 // relayout (Q,n,C) -> (n,Q,C), C <= 32
 // --------------------------------------------------------------------------------------------------
-constexpr int kRelT = 16;
+constexpr int kRelT = 16;           // samples per tile
+// vt vertices per tile: 16 for C >= 4, more for shorter rows so that a tile row read is >= 256 contiguous bytes
 __global__ __launch_bounds__(kBlock) void relayout_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                          int64_t Q, int64_t n, int C) {
-  __shared__ float tile[kRelT * kRelT * 32];
-  const int64_t i0 = (int64_t)blockIdx.x * kRelT, q0 = (int64_t)blockIdx.y * kRelT;
-  const int seg = kRelT * C;  // floats per (q, 16 vertices) or per (vertex, 16 q)
+                                                          int64_t Q, int64_t n, int C, int vt) {
+  __shared__ float tile[kRelT * kRelT * 32];          // vt * C <= 512 floats per sample row
+  const int64_t i0 = (int64_t)blockIdx.x * vt, q0 = (int64_t)blockIdx.y * kRelT;
+  const int seg = vt * C;             // floats per (sample, vt vertices)
   for (int e = threadIdx.x; e < kRelT * seg; e += kBlock) {
     const int q = e / seg, rem = e % seg;
     float v = 0.f;
@@ -18,12 +19,15 @@ __global__ __launch_bounds__(kBlock) void relayout_kernel(const float* __restric
     tile[e] = v;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kRelT * seg; e += kBlock) {
-    const int i = e / seg, rem = e % seg;
+  const int oseg = kRelT * C;         // floats per (vertex, 16 samples)
+  for (int e = threadIdx.x; e < vt * oseg; e += kBlock) {
+    const int i = e / oseg, rem = e % oseg;
     const int q = rem / C, c = rem % C;
-    if (i0 + i < n && q0 + q < Q) out[((i0 + i) * Q + q0) * C + rem] = tile[(q * kRelT + i) * C + c];
+    if (i0 + i < n && q0 + q < Q) out[((i0 + i) * Q + q0) * C + rem] = tile[(q * vt + i) * C + c];
   }
 }
+
+inline int relayout_vertex_tile(int C) { return C >= 4 ? 16 : (C >= 2 ? 32 : 64); }
 
 // --------------------------------------------------------------------------------------------------
 // pooling

@@ -329,9 +329,10 @@ int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int6
   if (C > 32) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "relayout: C=%d > 32", C);
   const int64_t gy = (Q + kRelT - 1) / kRelT;
   if (gy > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "relayout: Q too large");
-  const dim3 grid((unsigned)((n + kRelT - 1) / kRelT), (unsigned)gy);
+  const int vt = relayout_vertex_tile(C);
+  const dim3 grid((unsigned)((n + vt - 1) / vt), (unsigned)gy);
   ProfScope ps(TGCN_PROF_RELAYOUT, (hipStream_t)stream);
-  hipLaunchKernelGGL(relayout_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, in, out, Q, n, (int)C);
+  hipLaunchKernelGGL(relayout_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, in, out, Q, n, (int)C, vt);
   TGCN_CHECK_LAUNCH("tgcn_relayout_qnc_to_nqc_f32");
   return TGCN_OK;
 }
