@@ -30,7 +30,7 @@ extern "C" {
 #define TGCN_ERR_WORKSPACE (-3)   /* caller workspace too small */
 #define TGCN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
 
-#define TGCN_ABI_VERSION 2
+#define TGCN_ABI_VERSION 3
 
 /* One stored entry of the sparse operand: 8 bytes, read with a single load. */
 typedef struct tgcn_edge {
@@ -73,6 +73,25 @@ typedef struct tgcn_csr_sched {
   const int32_t* seg_slot;  /* [nseg] scratch slot, or -1: whole row, written directly */
   const int32_t* long_row;  /* [nlong] */
   const int32_t* long_slot; /* [nlong+1] first slot of each long row (slots of a row are consecutive, in column order) */
+  /* ---- ABI v3: sweep schedule of the long rows (sw_rounds == 0: absent, long rows are in the segment arrays above).
+   * Large operands only.  The rows with more than row_thresh entries are dealt, in order of decreasing length, to
+   * sw_nwg persistent 1024-thread workgroups per round; a row of more than ~1024 entries is cut into up to sw_slots/2 UNITS
+   * (entry p of the row belongs to unit p mod k), every unit owns one accumulator slot of lanes_per_row*4 floats in the
+   * workgroup's LDS, and the units of a workgroup are dealt to its sw_groups lane groups (8 slots per group).  Each lane group
+   * walks ONE contiguous stream of entries [sw_gptr[w*sw_groups+g], sw_gptr[w*sw_groups+g+1]) of sw_ent, stored in order of
+   * (column popularity panel, unit, column popularity): all workgroups resident on an XCD then sweep the dense operand from
+   * its most to its least referenced rows together, and a row of the dense operand fetched by one of them is served to the
+   * others by that XCD's L2.  The unit index (0..7 inside its lane group) rides in the top 4 bits of tgcn_edge.col, so the
+   * sweep needs fewer than 2^28 columns.  After the sweep the slots of a row are folded in unit order (deterministic). */
+  int32_t sw_rounds;        /* rounds per launch (0: no sweep) */
+  int32_t sw_nwg;           /* workgroups per round = grid.x of the sweep launch */
+  int32_t sw_groups;        /* lane groups per workgroup = 1024 / lanes_per_row */
+  int32_t sw_slots;         /* accumulator slots per workgroup = 8 * sw_groups */
+  const tgcn_edge* sw_ent;  /* [sw_gptr[last]] entries of the swept rows, col = column | unit << 28 */
+  const int32_t* sw_gptr;   /* [sw_rounds*sw_nwg*sw_groups + 1] */
+  const int32_t* sw_slot_row;   /* [sw_rounds*sw_nwg*sw_slots] row written from this slot (first unit of the row), or -1 */
+  const int32_t* sw_slot_chain; /* [sw_rounds*sw_nwg*sw_slots] offset into sw_chain of the row's other units, or -1 */
+  const int32_t* sw_chain;      /* per multi-unit row: count, then the slots of units 1..count in unit order */
 } tgcn_csr_sched;
 
 /* Batched dense operand: element (b, i, c) lives at ptr[b*batch_stride + i*row_stride + c]. */
@@ -95,12 +114,14 @@ int tgcn_abi_version(void);
 #define TGCN_PROF_SMALL 4
 #define TGCN_PROF_WGRAD 5
 #define TGCN_PROF_SMALL_BASIS 6
+#define TGCN_PROF_HOP_SWEEP 7   /* long rows of a hop on the sweep schedule (same hop as the TGCN_PROF_HOP launch that follows) */
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 
 /* Developer switches for A/B runs (tools/hop_bench.py, tools/proj_bench.py; every one is checked against the oracle in
  * tests/test_fuzz_parity.py).  Process-wide, same arithmetic, another kernel; returns TGCN_ERR_INVALID for unknown keys.
  *   "hop_variant"     0 shipped hop kernel; 1.. alternative unroll / row-interleave shapes of hop.h
+ *   "sweep_loads"     row loads in flight per lane of hop_sweep_kernel: 8 (default), 4 or 16
  *   "project_variant" 0 auto; 1 exact-fp32 streaming-W; 2 exact-fp32 W-resident with 16-row wave tiles; 3 bf16x3 always;
  *                     4 exact-fp32 auto; 5 vector-ALU narrow kernel wherever it applies
  *   "x3_form"         2 (default) bf16x3 with A fragments from registers for >= 96 output columns; 1 both operands via LDS

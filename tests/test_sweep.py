@@ -1,0 +1,174 @@
+"""Sweep schedule of the long rows (tgcn_csr_sched ABI v3, csrc/hop.h hop_sweep_kernel): the host-side builder is checked
+on the CPU by replaying its streams in numpy; the kernel is checked against the oracle with the schedule forced onto small
+operands (shipped: only operands with >= 8 M entries in long rows take it) and at full width through linearity / adjoint
+identities."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import cheb_oracle as O
+
+TOL = 1e-5
+
+
+def _hub_graph(n, rng, hubs):
+    deg = rng.integers(0, 20, n)
+    deg[rng.integers(0, n, n // 10)] = 0                       # isolated vertices
+    for h, d in hubs:
+        deg[h] = d
+    row = np.repeat(np.arange(n), deg)
+    col = rng.integers(0, n, row.shape[0])
+    col[rng.random(row.shape[0]) < 0.3] //= 50                  # popular columns
+    val = (rng.standard_normal(row.shape[0]) / 4).astype(np.float32)
+    return row, col, val
+
+
+def _replay(sw, X):
+    """what hop_sweep_kernel computes, in numpy: per lane group one stream, sums per unit slot, slots folded in unit order"""
+    G, SL = sw.groups, sw.slots
+    ent = sw.ent.cpu().numpy()
+    vals = sw.ent[:, 1].contiguous().view(torch.float32).cpu().numpy()
+    gptr, srow, sch, chain = (t.cpu().numpy() for t in (sw.gptr, sw.slot_row, sw.slot_chain, sw.chain))
+    out = {}
+    seen = 0
+    for wg in range(sw.rounds * sw.nwg):
+        acc = np.zeros((SL, X.shape[1]))
+        for g in range(G):
+            prev = (-1, -1)
+            for e in range(gptr[wg * G + g], gptr[wg * G + g + 1]):
+                c = int(ent[e, 0]) & 0xFFFFFFFF
+                j, c = c >> 28, c & ((1 << 28) - 1)
+                acc[g * 8 + j] += vals[e] * X[c]
+                seen += 1
+        for sl in range(SL):
+            r = srow[wg * SL + sl]
+            if r < 0:
+                continue
+            a = acc[sl].copy()
+            ch = sch[wg * SL + sl]
+            if ch >= 0:
+                for i in range(chain[ch]):
+                    a += acc[chain[ch + 1 + i]]
+            assert r not in out
+            out[int(r)] = a
+    return out, seen
+
+
+@pytest.mark.parametrize("lanes,nwg,unit", [(16, 4, 256), (4, 2, 64), (64, 3, 100)])
+def test_sweep_builder_replay_cpu(lanes, nwg, unit):
+    from tgcn_amd import graph
+    rng = np.random.default_rng(lanes)
+    n = 2500
+    row, col, val = _hub_graph(n, rng, hubs=((3, 2400), (77, 900), (1500, 5000), (2499, 333)) + tuple((int(h), 40 + int(h) % 300) for h in rng.integers(0, n, 60)))
+    op = graph.GraphOperand.from_coo(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val))
+    sw = graph.SweepSchedule.build(op.rowptr, op.edges, n, n, lanes, 32, nwg=nwg, unit=unit, panel_rows=97, force=True)
+    assert sw is not None and sw.groups == 1024 // lanes and sw.slots == 8 * sw.groups
+    deg = np.bincount(row, minlength=n)
+    long_rows = np.nonzero(deg > 32)[0]
+    X = rng.standard_normal((n, 3))
+    got, seen = _replay(sw, X)
+    assert seen == int(deg[long_rows].sum()) == sw.n_entries
+    assert sorted(got) == long_rows.tolist()                   # every long row is written exactly once, no short row
+    ref = O.coo_to_csr(row, col, val.astype(np.float64), n) @ X
+    for r in long_rows:
+        assert np.abs(got[r] - ref[r]).max() <= 1e-9 * max(1.0, np.abs(ref[r]).max())
+    # streams are ordered by (popularity panel, unit): the unit index never decreases inside a panel
+    cnt = np.bincount(col, minlength=n)
+    rank = np.empty(n, dtype=np.int64)
+    rank[np.argsort(-cnt, kind="stable")] = np.arange(n)
+    ent = sw.ent.numpy()
+    gptr = sw.gptr.numpy()
+    for s in range(0, len(gptr) - 1, 7):
+        c = ent[gptr[s]:gptr[s + 1], 0].astype(np.int64) & 0xFFFFFFFF
+        key = (rank[c & ((1 << 28) - 1)] // 97) * 8 + (c >> 28)
+        assert np.all(np.diff(key) >= 0)
+
+
+def test_sweep_not_built_for_small_operands():
+    from tgcn_amd import graph
+    rng = np.random.default_rng(1)
+    row, col, val = _hub_graph(500, rng, hubs=((3, 400),))
+    op = graph.GraphOperand.from_coo(500, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val))
+    assert graph.SweepSchedule.build(op.rowptr, op.edges, 500, 500, 16, 32) is None
+
+
+@pytest.fixture
+def forced_sweep(monkeypatch):
+    from tgcn_amd import graph
+    monkeypatch.setattr(graph, "SWEEP_MIN_ENTRIES", 1)
+    monkeypatch.setattr(graph, "SWEEP_WORKGROUPS", 6)
+    monkeypatch.setattr(graph, "SWEEP_UNIT", 200)
+    return graph
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,n,C", [(1, 3000, 64), (3, 2000, 16), (2, 2500, 32), (1, 1800, 128), (2, 1500, 256), (1, 2200, 60), (2, 4000, 20)])
+def test_sweep_hop_vs_oracle(nb, n, C, gpu_device, forced_sweep):
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(n + C)
+    hubs = ((5, 700), (n - 1, 1300), (11, 9000), (n // 2, 33), (n // 3, 4100)) + tuple((int(h), 33 + int(h) % 500) for h in rng.integers(20, n - 20, 80))
+    row, col, val = _hub_graph(n, rng, hubs)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    op = forced_sweep.GraphOperand.from_coo(n, dev(row), dev(col), dev(val))
+    sched = op.schedule_for(C, True)
+    assert sched.sweep is not None and sched.nseg == 0 and sched.sweep.rounds >= 1
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((nb, n, C)).astype(np.float32)
+    z = rng.standard_normal((nb, n, C)).astype(np.float32)
+    s = O._apply(L, x)
+    y = F.csr_hop(op, dev(x))
+    assert rel_err(y.cpu().numpy(), s) <= TOL
+    y, p = F.csr_hop(op, dev(x), z=dev(z), alpha=2.0, beta=-1.0, want_p=True)
+    assert rel_err(p.cpu().numpy(), s) <= TOL
+    assert rel_err(y.cpu().numpy(), 2 * s - z) <= TOL
+    # fixed summation order: bitwise identical run to run
+    assert torch.equal(y, F.csr_hop(op, dev(x), z=dev(z), alpha=2.0, beta=-1.0))
+    # rows of X holding Inf / NaN propagate as in a per-entry evaluation
+    x2 = x.copy()
+    x2[0, 7, :] = np.inf
+    ref = O._apply(L, x2.astype(np.float64))
+    got = F.csr_hop(op, dev(x2)).cpu().numpy()
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+
+
+@pytest.mark.gpu
+def test_sweep_unaligned_rows_take_the_segment_path(gpu_device, forced_sweep):
+    """C % 4 != 0 (scalar loads) cannot use the sweep kernel: such calls get a schedule with segments instead"""
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(9)
+    n = 1500
+    row, col, val = _hub_graph(n, rng, ((5, 900), (9, 2000)))
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    op = forced_sweep.GraphOperand.from_coo(n, dev(row), dev(col), dev(val))
+    assert op.schedule_for(15, False).sweep is None
+    x = rng.standard_normal((2, n, 15)).astype(np.float32)
+    assert rel_err(F.csr_hop(op, dev(x)).cpu().numpy(), O._apply(O.coo_to_csr(row, col, val, n), x)) <= TOL
+
+
+@pytest.mark.gpu
+def test_sweep_linearity_adjoint_large(gpu_device, monkeypatch):
+    """shipped thresholds, an operand large enough to take the sweep by itself (12 M entries in long rows)"""
+    from tgcn_amd import functional as F, graph
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, m, C = 600_000, 14_000_000, 64
+    row = (torch.rand(m, device="cuda", generator=g) ** 4 * n).long().clamp_(max=n - 1)          # long rows
+    col = (torch.rand(m, device="cuda", generator=g) ** 3 * n).long().clamp_(max=n - 1)          # popular columns
+    val = torch.randn(m, device="cuda", generator=g) * 0.1
+    op = graph.GraphOperand.from_coo(n, row, col, val)
+    assert op.schedule_for(C, True).sweep is not None
+    x1 = torch.randn(1, n, C, device="cuda", generator=g)
+    x2 = torch.randn(1, n, C, device="cuda", generator=g)
+    y1 = F.csr_hop(op, x1)
+    lhs = F.csr_hop(op, 0.5 * x1 + x2)
+    rhs = 0.5 * y1 + F.csr_hop(op, x2)
+    assert rel_err(lhs.cpu().numpy(), rhs.cpu().numpy()) <= TOL
+    opT = op.transpose()
+    a = (y1.double() * x2.double()).sum()
+    b = (x1.double() * F.csr_hop(opT, x2).double()).sum()
+    assert abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1.0)
+    # same rows as the segment schedule gives (different summation order: tolerance, not bits)
+    monkeypatch.setattr(graph, "SWEEP", False)
+    op2 = graph.GraphOperand.from_coo(n, row, col, val)
+    assert op2.schedule_for(C, True).sweep is None
+    assert rel_err(F.csr_hop(op2, x1).cpu().numpy(), y1.cpu().numpy()) <= TOL

@@ -314,6 +314,135 @@ __global__ __launch_bounds__(kBlock) void hop_fixup_kernel(const HopParams p) {
   if (valid && c0 < p.C) finish_row<VEC, 0>(p, b, row, c0, acc);
 }
 
+// --------------------------------------------------------------------------------------------------
+// sweep: long rows of large operands, accumulators in LDS, entries walked in order of column popularity
+// --------------------------------------------------------------------------------------------------
+// (include/tgcn_hip.h, tgcn_csr_sched ABI v3.)  One 1024-thread workgroup per CU; a lane group owns 8 accumulator slots in
+// LDS (lane t owns floats 4t..4t+3 of each: private words, no atomics, no barrier in the loop) and walks one contiguous
+// stream of entries sorted by (column popularity panel, unit, column popularity).  Consecutive entries of one unit are
+// summed in registers and added to the unit's slot when the unit changes.  Measured motive: on the 160 M-entry R-MAT the
+// column-ordered segments fetched 19.5 GB per launch for the rows above 32 entries, of which a trace-driven model of the
+// eight L2s (tools/sim) attributes 9 GB to rows of X re-fetched by workgroups that reach the same columns at different
+// times; with every resident workgroup sweeping the columns in the same order the model fetches 10.5 GB.
+struct SweepParams {
+  const tgcn_edge* ent;
+  const int32_t* gptr;
+  const int32_t* slot_row;
+  const int32_t* slot_chain;
+  const int32_t* chain;
+  int32_t rounds, nwg;
+};
+
+constexpr int kSweepBlock = 1024, kSweepSlotsPerGroup = 8, kSweepUnitShift = 28, kSweepColMask = (1 << kSweepUnitShift) - 1;
+
+template <int LPR, int NTM, int UU>
+__global__ __launch_bounds__(kSweepBlock) void hop_sweep_kernel(const HopParams p, const SweepParams s) {
+  constexpr int VEC = 4, G = kSweepBlock / LPR, SPG = kSweepSlotsPerGroup, SLOTS = G * SPG, ROWF = LPR * VEC;
+  constexpr int U = LPR < UU ? LPR : UU;   // row loads in flight per lane: one workgroup per CU, so 8 (128 KB per CU)
+  extern __shared__ float sweep_acc[];                   // SLOTS x ROWF floats = 128 KB
+  const int tid = threadIdx.x;
+  const int t = tid % LPR;
+  const int g = tid / LPR;
+  const int b = blockIdx.y;
+  const int c0 = t * VEC;
+  const bool cact = c0 < p.C;
+  const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
+  float* mine = sweep_acc + (g * SPG) * ROWF + c0;        // this lane's words of its group's 8 slots
+  for (int round = 0; round < s.rounds; ++round) {
+    const int wg = round * s.nwg + (int)blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < SPG; ++j) *reinterpret_cast<float4*>(mine + j * ROWF) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int e0 = s.gptr[wg * G + g], e1 = s.gptr[wg * G + g + 1];
+    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int e = e0; e < e1; e += LPR) {
+      int my_c = 0;
+      float my_v = 0.f;
+      if (e + t < e1) load_edge<NTM>(s.ent, e + t, my_c, my_v);
+      const int cnt = min(LPR, e1 - e);
+#pragma unroll
+      for (int j0 = 0; j0 < LPR; j0 += U) {              // fully unrolled: the broadcast lane is an immediate
+        if (j0 < cnt) {
+          float xv[U][VEC];
+          float vv[U];
+          int uu[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int c = group_bcast<LPR>(my_c, j0 + u);
+            vv[u] = __int_as_float(group_bcast<LPR>(__float_as_int(my_v), j0 + u));
+            uu[u] = (int)((unsigned)c >> kSweepUnitShift);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) xv[u][i] = 0.f;
+            if (j0 + u < cnt) load_vec<VEC>(Xc + (int64_t)(c & kSweepColMask) * p.x_ld, xv[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (j0 + u < cnt) {
+              if (uu[u] != cur) {                          // same for the lanes of a group: next unit of this group's stream
+                float4* sl = reinterpret_cast<float4*>(mine + cur * ROWF);
+                float4 o = *sl;
+                o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
+                *sl = o;
+                cur = uu[u];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+              }
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vv[u], xv[u][i], acc[i]);
+            }
+          }
+        }
+      }
+    }
+    {
+      float4* sl = reinterpret_cast<float4*>(mine + cur * ROWF);
+      float4 o = *sl;
+      o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
+      *sl = o;
+    }
+    __syncthreads();
+    // fold the units of each row in unit order and write the row: the group that owns a row's first unit does it
+#pragma unroll 1
+    for (int j = 0; j < SPG; ++j) {
+      const int sl = g * SPG + j;
+      const int row = s.slot_row[(int64_t)wg * SLOTS + sl];
+      if (row < 0) continue;                               // same for the lanes of a group
+      float a[VEC];
+      {
+        const float4 o = *reinterpret_cast<const float4*>(sweep_acc + sl * ROWF + c0);
+        a[0] = o.x; a[1] = o.y; a[2] = o.z; a[3] = o.w;
+      }
+      const int ch = s.slot_chain[(int64_t)wg * SLOTS + sl];
+      if (ch >= 0) {
+        const int n_more = s.chain[ch];
+        for (int i = 0; i < n_more; ++i) {
+          const int s2 = s.chain[ch + 1 + i];
+          const float4 o = *reinterpret_cast<const float4*>(sweep_acc + s2 * ROWF + c0);
+          a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w;
+        }
+      }
+      if (cact) finish_row<VEC, NTM>(p, b, row, c0, a);
+    }
+    __syncthreads();
+  }
+}
+
+template <int LPR>
+inline void launch_sweep(hipStream_t st, const HopParams& p, const SweepParams& s, int nb) {
+  constexpr int lds = (kSweepBlock / LPR) * kSweepSlotsPerGroup * LPR * 4 * (int)sizeof(float);
+  const int v = g_sweep_loads.load();        // developer A/B (tools/hop_bench.py): row loads in flight per lane
+  if (v == 4) {
+    allow_large_lds((const void*)hop_sweep_kernel<LPR, 0, 4>, lds);
+    hipLaunchKernelGGL((hop_sweep_kernel<LPR, 0, 4>), dim3((unsigned)s.nwg, (unsigned)nb), dim3(kSweepBlock), lds, st, p, s);
+  } else if (v == 16) {
+    allow_large_lds((const void*)hop_sweep_kernel<LPR, 0, 16>, lds);
+    hipLaunchKernelGGL((hop_sweep_kernel<LPR, 0, 16>), dim3((unsigned)s.nwg, (unsigned)nb), dim3(kSweepBlock), lds, st, p, s);
+  } else {
+    allow_large_lds((const void*)hop_sweep_kernel<LPR, 0, 8>, lds);
+    hipLaunchKernelGGL((hop_sweep_kernel<LPR, 0, 8>), dim3((unsigned)s.nwg, (unsigned)nb), dim3(kSweepBlock), lds, st, p, s);
+  }
+}
+
 struct HopGeom {
   int vec, lpr, nchunks, cpad;
 };
@@ -373,7 +502,20 @@ inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3
 template <int L> struct HopRows { static constexpr int value = (L == 64) ? 4 : 1; };
 
 template <int VEC>
-int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
+int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid, const SweepParams* sw = nullptr) {
+  if (sw && sw->rounds > 0) {
+    if (VEC != 4) TGCN_FAIL(TGCN_ERR_INVALID, "hop: the sweep schedule needs 16-byte aligned rows");
+    ProfScope ps(TGCN_PROF_HOP_SWEEP, st);
+    switch (lpr) {
+      case 4: launch_sweep<4>(st, p, *sw, (int)grid.y); break;
+      case 8: launch_sweep<8>(st, p, *sw, (int)grid.y); break;
+      case 16: launch_sweep<16>(st, p, *sw, (int)grid.y); break;
+      case 32: launch_sweep<32>(st, p, *sw, (int)grid.y); break;
+      case 64: launch_sweep<64>(st, p, *sw, (int)grid.y); break;
+      default: TGCN_FAIL(TGCN_ERR_INVALID, "hop: sweep schedule with %d lanes per row", lpr);
+    }
+    TGCN_CHECK_LAUNCH("tgcn_csr_hop_f32 (sweep)");
+  }
 #define TGCN_HOP_CASE(L)                                                                    \
   case L: {                                                                                 \
     { ProfScope ps(TGCN_PROF_HOP, st);                                                      \

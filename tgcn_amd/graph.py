@@ -16,6 +16,13 @@ HUGE_SLOTS = 64         # long rows with more segments than this get a whole wor
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
 DENSE_MAX_N = 256       # operands up to this size that store >= 1/4 of their entries also keep a dense copy
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
+# sweep schedule of the long rows (include/tgcn_hip.h, tgcn_csr_sched ABI v3; kernel: csrc/hop.h hop_sweep_kernel)
+SWEEP = True                    # developer switch
+SWEEP_MIN_ENTRIES = 8_000_000   # entries in rows above ROW_THRESH from which the sweep replaces the segments (smaller operands sit in L2 / the Infinity Cache anyway)
+SWEEP_UNIT = 1024               # entries per unit: longer rows are cut so that the lane groups of a workgroup stay balanced
+SWEEP_WORKGROUPS = 256          # persistent workgroups per round: one per CU of an MI355X
+SWEEP_PANEL_BYTES = 2 << 20     # rows of X per popularity panel = this / row bytes: half of one XCD's L2
+SWEEP_SLOTS_PER_GROUP = 8
 
 
 def _as_i32(t):
@@ -31,13 +38,16 @@ def _check_range(row, col, n, ncol):
 class Schedule:
     """Work schedule for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
 
-    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None):
+    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None, sweep=False, n_cols=None):
         row_thresh = ROW_THRESH if row_thresh is None else row_thresh
         seg_len = max(SEG_LEN if seg_len is None else seg_len, 1)
         dev = rowptr.device
         gpb = 256 // lanes_per_row
         deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
         is_seg = deg > row_thresh
+        self.sweep = None
+        if sweep and edges is not None and lanes_per_row >= 4:
+            self.sweep = SweepSchedule.build(rowptr, edges, n, n if n_cols is None else n_cols, lanes_per_row, row_thresh)
         # ---- short rows: nnz-balanced row blocks
         cost = torch.where(is_seg, torch.zeros_like(deg), deg) + ROW_COST
         cum = torch.cumsum(cost, 0)
@@ -54,6 +64,8 @@ class Schedule:
         self.nblk = nblk
         # ---- longer rows: segments, long rows (several segments) first by decreasing segment count
         seg_rows = is_seg.nonzero().flatten()
+        if self.sweep is not None:          # the long rows are on the sweep schedule: no segments
+            seg_rows = seg_rows[:0]
         z1 = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nseg = self.nlong = self.nhuge = self.npartial = 0
         self.seg_row = self.seg_e0 = self.seg_e1 = self.seg_slot = self.long_row = z1
@@ -93,10 +105,138 @@ class Schedule:
         self.lanes_per_row = lanes_per_row
         self.row_thresh = row_thresh
         self.seg_len = seg_len
+        sw = self.sweep
         self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, 0,
                                        self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
                                        self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
-                                       self.long_slot.data_ptr())
+                                       self.long_slot.data_ptr(),
+                                       sw.rounds if sw else 0, sw.nwg if sw else 0, sw.groups if sw else 0, sw.slots if sw else 0,
+                                       sw.ent.data_ptr() if sw else None, sw.gptr.data_ptr() if sw else None,
+                                       sw.slot_row.data_ptr() if sw else None, sw.slot_chain.data_ptr() if sw else None,
+                                       sw.chain.data_ptr() if sw else None)
+
+
+class SweepSchedule:
+    """Sweep schedule of the rows above the row threshold (tgcn_csr_sched ABI v3, include/tgcn_hip.h): which workgroup,
+    lane group and accumulator slot every (row, unit) gets, and the entries of every lane group as one stream in order of
+    (column popularity panel, unit, column popularity).  Index plumbing on torch tensors, any device."""
+
+    @staticmethod
+    def build(rowptr, edges, n, n_cols, lanes_per_row, row_thresh, nwg=None, unit=None, panel_rows=None, force=False):
+        dev = rowptr.device
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        rows = (deg > row_thresh).nonzero().flatten()
+        if rows.numel() == 0 or n_cols >= (1 << 28) or lanes_per_row < 4:
+            return None
+        if not force and (not SWEEP or int(deg[rows].sum().item()) < SWEEP_MIN_ENTRIES):
+            return None
+        nwg = SWEEP_WORKGROUPS if nwg is None else nwg
+        unit = SWEEP_UNIT if unit is None else unit
+        G = 1024 // lanes_per_row
+        spg = SWEEP_SLOTS_PER_GROUP
+        slots = spg * G
+        P = max(1, SWEEP_PANEL_BYTES // (lanes_per_row * 16)) if panel_rows is None else panel_rows
+        self = SweepSchedule()
+        # rows by decreasing length; k units per row
+        order = torch.argsort(deg[rows], descending=True, stable=True)
+        rows = rows[order]
+        dl = deg[rows]
+        nL = rows.numel()
+        k = ((dl + unit - 1) // unit).clamp_(1, slots // 2)
+        cu = torch.cumsum(k, 0) - k
+        ar = torch.arange(nL, device=dev, dtype=torch.int64)
+        fill = 0.97
+        while True:
+            cap = max(int(nwg * slots * fill), 1)
+            rnd = cu // cap
+            R = int(rnd[-1].item()) + 1
+            first = torch.searchsorted(rnd, torch.arange(R, device=dev, dtype=torch.int64))
+            idx = ar - first[rnd]
+            pos = idx % (2 * nwg)
+            wg = torch.where(pos < nwg, pos, 2 * nwg - 1 - pos)        # snake: every workgroup gets the same mix of row lengths
+            wgid = rnd * nwg + wg
+            used = torch.zeros(R * nwg, dtype=torch.int64, device=dev).index_add_(0, wgid, k)
+            if int(used.max().item()) <= slots:
+                break
+            fill *= 0.9
+            if fill < 0.05:
+                return None
+        # units: (row, residue); unit u of row i holds the entries p = u, u + k, u + 2k, ...
+        nU = int(k.sum().item())
+        u_row = torch.repeat_interleave(ar, k)
+        u_res = torch.arange(nU, device=dev, dtype=torch.int64) - cu[u_row]
+        u_len = (dl[u_row] - u_res + k[u_row] - 1) // k[u_row]
+        u_wg = wgid[u_row]
+        # inside a workgroup: units by decreasing length, dealt to the lane groups in snake order, 8 per group at most
+        maxlen = int(u_len.max().item()) + 1
+        uo = torch.argsort(u_wg * maxlen + (maxlen - 1 - u_len), stable=True)
+        wg_sorted = u_wg[uo]
+        wfirst = torch.searchsorted(wg_sorted, torch.arange(R * nwg, device=dev, dtype=torch.int64))
+        uidx = torch.arange(nU, device=dev, dtype=torch.int64) - wfirst[wg_sorted]
+        j_s = uidx // G
+        gpos = uidx % G
+        g_s = torch.where(j_s % 2 == 0, gpos, G - 1 - gpos)
+        u_j = torch.empty(nU, dtype=torch.int64, device=dev)
+        u_g = torch.empty(nU, dtype=torch.int64, device=dev)
+        u_j[uo] = j_s
+        u_g[uo] = g_s
+        assert int(u_j.max().item()) < spg
+        u_slot = u_g * spg + u_j                                   # slot inside the workgroup
+        # slot tables
+        self.slot_row = torch.full((R * nwg * slots,), -1, dtype=torch.int32, device=dev)
+        self.slot_chain = torch.full((R * nwg * slots,), -1, dtype=torch.int32, device=dev)
+        head = u_res == 0
+        self.slot_row[(u_wg * slots + u_slot)[head]] = rows[u_row[head]].to(torch.int32)
+        multi = k > 1
+        if bool(multi.any()):
+            km = k[multi]
+            coff = torch.cumsum(km, 0) - km                        # per multi-unit row: 1 count + (k-1) slots = k ints
+            chain = torch.empty(int(km.sum().item()), dtype=torch.int32, device=dev)
+            chain[coff] = (km - 1).to(torch.int32)
+            row_coff = torch.full((nL,), -1, dtype=torch.int64, device=dev)
+            row_coff[multi] = coff
+            tail = (u_res > 0)
+            chain[(row_coff[u_row] + u_res)[tail]] = u_slot[tail].to(torch.int32)
+            hm = head & multi[u_row]
+            self.slot_chain[(u_wg * slots + u_slot)[hm]] = row_coff[u_row[hm]].to(torch.int32)
+            self.chain = chain
+        else:
+            self.chain = torch.zeros(1, dtype=torch.int32, device=dev)
+        # entries of the swept rows
+        starts = rowptr[rows].to(torch.int64)
+        e_rowl = torch.repeat_interleave(ar, dl)
+        nE = int(dl.sum().item())
+        e_pos = torch.arange(nE, device=dev, dtype=torch.int64) - torch.repeat_interleave(torch.cumsum(dl, 0) - dl, dl)
+        e_idx = starts[e_rowl] + e_pos
+        e_unit = cu[e_rowl] + e_pos % k[e_rowl]
+        del e_pos, e_rowl
+        col = edges[: , 0][e_idx].to(torch.int64)
+        cnt = torch.bincount(edges[: max(int(rowptr[-1].item()), 1), 0].to(torch.int64), minlength=n_cols)
+        corder = torch.argsort(cnt, descending=True, stable=True)
+        crank = torch.empty(n_cols, dtype=torch.int64, device=dev)
+        crank[corder] = torch.arange(n_cols, device=dev, dtype=torch.int64)
+        del cnt, corder
+        cr = crank[col]
+        del crank
+        npan = (n_cols + P - 1) // P + 1
+        stream = u_wg[e_unit] * G + u_g[e_unit]
+        key = (stream * npan + cr // P) * spg + u_j[e_unit]
+        o1 = torch.argsort(cr, stable=True)
+        o2 = torch.argsort(key[o1], stable=True)
+        o = o1[o2]
+        del o1, o2, cr, key
+        ent = torch.empty((max(nE, 1), 2), dtype=torch.int32, device=dev)
+        packed = col[o] | (u_j[e_unit[o]] << 28)
+        ent[:nE, 0] = packed.to(torch.int32) if packed.numel() == 0 else torch.where(packed >= (1 << 31), packed - (1 << 32), packed).to(torch.int32)
+        ent[:nE, 1] = edges[:, 1][e_idx[o]]
+        self.ent = ent
+        per_stream = torch.bincount(stream, minlength=R * nwg * G)
+        gptr = torch.zeros(R * nwg * G + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(per_stream, 0, out=gptr[1:])
+        self.gptr = _as_i32(gptr)
+        self.rounds, self.nwg, self.groups, self.slots = R, nwg, G, slots
+        self.n_rows, self.n_entries, self.n_units, self.panel_rows = nL, nE, nU, P
+        return self
 
 
 class GraphOperand:
@@ -242,14 +382,20 @@ class GraphOperand:
         row, col, val = self.coo()
         return GraphOperand.from_coo(self.n, row, col, val, device)
 
-    def schedule(self, lanes_per_row):
-        s = self._sched.get(lanes_per_row)
+    def schedule(self, lanes_per_row, sweep=False):
+        """sweep: the caller's rows are 16-byte aligned and fit one lane group (<= 256 floats), so the long rows may go on the
+        sweep schedule (it is only built for large operands, see SweepSchedule.build)."""
+        s = self._sched.get((lanes_per_row, sweep))
         if s is None:
-            s = self._sched[lanes_per_row] = Schedule(self.rowptr, self.n, lanes_per_row, edges=self.edges)
+            s = self._sched[(lanes_per_row, sweep)] = Schedule(self.rowptr, self.n, lanes_per_row, edges=self.edges, sweep=sweep,
+                                                               n_cols=self.n_cols)
         return s
 
     def schedule_for(self, C_row, aligned16=True):
-        return self.schedule(_lib.lib().tgcn_hop_lanes_per_row(int(C_row), 1 if aligned16 else 0))
+        L = _lib.lib()
+        al = 1 if aligned16 else 0
+        sweep = L.tgcn_hop_vec_width(int(C_row), al) == 4 and int(C_row) <= 256
+        return self.schedule(L.tgcn_hop_lanes_per_row(int(C_row), al), sweep)
 
     def to_scipy(self):
         import scipy.sparse as sp
