@@ -8,8 +8,10 @@ A "step" is ONE forward of the layer over one batch of synthetic input resident 
         time steps  -> 4 hops x 16 time steps of CSR x (n x 64) + the (K*64) x 64 projection.
   cfg4: sheet mesh n=90k / nnz~0.9M, TGCNCheb_H(L, 1, 32, 5, 1200), q=1.
   cfg3: MNIST grid n=784, TGCNCheb_H(L, 1, 64, 5, 28), q=64.      cfg2: GCNCheb(L, 1, 64, 5), q=128.
-N > 1 (driver-launched with torch.distributed.run): the path shards by time step -- every rank holds the CSR and
-processes its own q time steps, no data-path collective -- weak scaling; value is the whole-job aggregate.
+N > 1 (driver-launched with torch.distributed.run): STRONG scaling on the named shape -- the q = T = 16 time steps of the
+workload are split over the ranks (16/N each; every rank holds the CSR, no data-path collective), value is the whole-job
+aggregate.  --shard vertex / hybrid run the vertex-sharded layer (halo / all-gather exchange per hop) on the same shape;
+--scaling weak keeps 16 time steps per rank instead.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = hop_kernel,
 algorithmic bytes per launch / mean launch duration from hipEvents recorded around every hop launch of the timed
@@ -107,6 +109,37 @@ def make_input(op, spec, device, seed):
     return torch.randn(shape, device=device, generator=g)
 
 
+def measured_copy_gbps(device, nbytes=2 << 30):
+    """device-to-device copy rate of this box (read + write bytes per second): the second denominator SURVEY.md 8(d) asks for"""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    best = 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
+
+
+def scipy_baseline(op, spec, x, cols=8):
+    """Single-thread scipy CSR, like the reference's numpy path (gcn/graph.py:256-265: Xt[k] = 2 L^k X - Xt[k-2] with
+    scipy's .dot): the K-hop recursion of oracle.cheb_oracle.graph_chebyshev on `cols` of the C_in*H columns of ONE sample."""
+    from oracle import cheb_oracle as O
+    L = op.to_scipy().astype(np.float32)
+    C_row = x[0].reshape(op.n, -1).shape[1]
+    cols = min(cols, C_row)
+    X = x[0].reshape(op.n, -1)[:, :cols].float().cpu().numpy()
+    t0 = time.perf_counter()
+    O.graph_chebyshev(L, X, spec["K"])
+    dt = time.perf_counter() - t0
+    units = op.nnz * (spec["K"] - 1) * spec["H"] * cols / C_row
+    return dict(value=units / dt / 1e9, unit="G edge\u00b7timesteps/s", cores=1, kind="port",
+                sample="%d of the %d columns of 1 of %d samples, K=%d recursion only (no projection), scipy CSR .dot single thread as gcn/graph.py:256-265, %.1f s" % (cols, C_row, spec["q"], spec["K"], dt))
+
+
 def cpu_baseline(op, spec, layer, x, budget_q=1):
     """oracle/cheb_ref.c (reference algorithm: full stack + unfolded weights) on the host cores, on `budget_q`
     of the q samples of the same workload."""
@@ -139,7 +172,8 @@ def main():
     ap.add_argument("--vertices", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
     ap.add_argument("--entries", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--shard", default="time", choices=["time", "vertex", "hybrid"], help="N > 1: time steps per rank (no collective, weak scaling); vertex rows per rank with a halo / all-gather exchange per hop (strong scaling); hybrid: --vertex-shards ranks share a graph, groups split the time steps")
+    ap.add_argument("--shard", default="time", choices=["time", "vertex", "hybrid"], help="N > 1: time steps split over the ranks (no collective); vertex rows per rank with a halo / all-gather exchange per hop; hybrid: --vertex-shards ranks share a graph, groups split the time steps")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1, time sharding: strong = the workload's q time steps split over the ranks (default); weak = q time steps per rank")
     ap.add_argument("--vertex-shards", type=int, default=2, help="ranks per graph copy for --shard hybrid")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--project-variant", type=int, default=None, help="developer: tgcn_set_tuning(project_variant, v)")
@@ -167,6 +201,12 @@ def main():
     if args.project_variant is not None:
         _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", args.project_variant))
     op, spec = build_workload(args.workload, args.labeling, device, args.vertices, args.entries)
+    q_total = spec["q"]
+    strong_time = world > 1 and args.shard == "time" and args.scaling == "strong" and spec["q"] >= world
+    if strong_time:
+        from tgcn_amd.dist import shard_time_steps
+        mine = shard_time_steps(spec["q"], rank, world)
+        spec["q"] = mine.stop - mine.start
     K, q, H = spec["K"], spec["q"], spec["H"]
     vertex_mode = world > 1 and args.shard in ("vertex", "hybrid")
     ngroups = 1
@@ -229,10 +269,14 @@ def main():
         dt = float(tmax.item())
 
     units_per_step = op.nnz * (K - 1) * q * H            # edge.timesteps per forward per rank
-    value = (ngroups if vertex_mode else world) * units_per_step * args.steps / dt / 1e9   # vertex mode: ONE graph per group of ranks
+    if strong_time:
+        value = op.nnz * (K - 1) * q_total * H * args.steps / dt / 1e9                      # the ranks split ONE q_total-step forward
+    else:
+        value = (ngroups if vertex_mode else world) * units_per_step * args.steps / dt / 1e9   # vertex mode: ONE graph per group of ranks
 
     # ---- roofline of the dominant kernel (hop_kernel): algorithmic bytes per launch / mean launch duration
-    hop_ms = [ms for kind, ms in prof if kind == 0]
+    hop_ms = [ms for kind, ms in prof if kind == 0]          # one per hop: short rows (+ segments when the sweep is off)
+    sweep_ms = [ms for kind, ms in prof if kind == 7]        # one per hop when the long rows are on the sweep schedule
     proj_ms = [ms for kind, ms in prof if kind == 2]
     fix_ms = [ms for kind, ms in prof if kind == 1]
     C_row = H * spec["f"]
@@ -257,16 +301,29 @@ def main():
                         note="whole layer in one launch; hop tensors never leave LDS, so the HBM roofline on recursion bytes is nominal")
     if hop_ms:
         bytes_per_launch = bytes_recursion / n_hop_launches
-        mean_ms = float(np.mean(hop_ms))
+        # a hop is hop_sweep_kernel (rows above 32 entries) followed by hop_kernel (the other rows): its duration is their sum
+        mean_ms = (float(np.sum(hop_ms)) + float(np.sum(sweep_ms))) / len(hop_ms)
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
+        # HBM-side bytes per hop from the rocprofv3 --pmc passes of THIS code (tools/collect_traffic.sh writes the file with
+        # the hash of the kernel sources it profiled); a file taken from other sources is stale and reported as null
         traffic = None
+        traffic_note = "no counter file for this workload"
         tpath = ""
         if args.vertices is None and args.entries is None and not vertex_mode:
             tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, args.labeling))
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_hop_launch")
-        roofline = dict(bound="hbm", kernel="hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+            tj = json.load(open(tpath))
+            if tj.get("source_hash") == _lib.source_hash():
+                traffic = tj.get("hbm_bytes_per_hop_launch")
+                traffic_note = "%s (source hash %s)" % (os.path.relpath(tpath, ROOT), tj.get("source_hash"))
+            else:
+                traffic_note = "%s is from other kernel sources (%s, now %s): stale, not reported" % (os.path.relpath(tpath, ROOT), tj.get("source_hash"), _lib.source_hash())
+        copy_gbps = measured_copy_gbps(device)
+        roofline = dict(bound="hbm", kernel="hop_sweep_kernel + hop_kernel (one hop)" if sweep_ms else "hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_note,
+                        copy_peak_measured=round(copy_gbps, 1), frac_of_copy_peak=round(achieved / copy_gbps, 4),
+                        sweep_kernel_mean_ms=round(float(np.mean(sweep_ms)), 4) if sweep_ms else None,
+                        row_kernel_mean_ms=round(float(np.mean(hop_ms)), 4),
                         algorithmic_bytes_per_launch=int(bytes_per_launch), launches_per_step=n_hop_launches,
                         path="project-first (hops on C_out-wide rows)" if pf_path else "hops-first",
                         mean_launch_ms=round(mean_ms, 4), hop_ms_per_step=round(float(np.sum(hop_ms)) / args.steps, 3),
@@ -280,13 +337,14 @@ def main():
         err = float(np.abs(got - ref_out).max() / np.abs(ref_out).max())
         cpu["gpu_vs_cpu_rel_err"] = err
         assert err <= 1e-5, "GPU result differs from the CPU restatement: %g" % err
+        cpu["scipy_single_thread"] = scipy_baseline(op, spec, x)
 
     if rank == 0:
         line = dict(metric=baseline_metric(), value=round(value, 3), unit="G edge\u00b7timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if (vertex_mode and ngroups == 1) else "weak", vs_baseline=None,
+                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if ((vertex_mode and ngroups == 1) or strong_time or world == 1) else "weak", vs_baseline=None,
                     dtype="f32", data="synthetic",
                     config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
-                                sharding=(("%d group(s) x %d vertex shards, %s exchange per hop inside a group" % (ngroups, sh.world, sh.exchange)) if ngroups > 1 else ("vertex rows across ranks, %s exchange per hop" % sh.exchange)) if vertex_mode else ("time steps across ranks, CSR replicated, no collective" if world > 1 else "single GPU"),
+                                sharding=(("%d group(s) x %d vertex shards, %s exchange per hop inside a group" % (ngroups, sh.world, sh.exchange)) if ngroups > 1 else ("vertex rows across ranks, %s exchange per hop" % sh.exchange)) if vertex_mode else (("the %d time steps of the workload split over %d ranks (%d on rank 0), CSR replicated, no collective" % (q_total, world, q) if strong_time else "%d time steps per rank, CSR replicated, no collective" % q) if world > 1 else "single GPU"),
                                 nnz=op.nnz, n=op.n),
                     roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line))

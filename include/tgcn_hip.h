@@ -75,23 +75,21 @@ typedef struct tgcn_csr_sched {
   const int32_t* long_slot; /* [nlong+1] first slot of each long row (slots of a row are consecutive, in column order) */
   /* ---- ABI v3: sweep schedule of the long rows (sw_rounds == 0: absent, long rows are in the segment arrays above).
    * Large operands only.  The rows with more than row_thresh entries are dealt, in order of decreasing length, to
-   * sw_nwg persistent 1024-thread workgroups per round; a row of more than ~1024 entries is cut into up to sw_slots/2 UNITS
-   * (entry p of the row belongs to unit p mod k), every unit owns one accumulator slot of lanes_per_row*4 floats in the
-   * workgroup's LDS, and the units of a workgroup are dealt to its sw_groups lane groups (8 slots per group).  Each lane group
-   * walks ONE contiguous stream of entries [sw_gptr[w*sw_groups+g], sw_gptr[w*sw_groups+g+1]) of sw_ent, stored in order of
-   * (column popularity panel, unit, column popularity): all workgroups resident on an XCD then sweep the dense operand from
-   * its most to its least referenced rows together, and a row of the dense operand fetched by one of them is served to the
-   * others by that XCD's L2.  The unit index (0..7 inside its lane group) rides in the top 4 bits of tgcn_edge.col, so the
-   * sweep needs fewer than 2^28 columns.  After the sweep the slots of a row are folded in unit order (deterministic). */
+   * sw_nwg persistent 1024-thread workgroups per round, sw_slots rows each; every row owns one accumulator slot of
+   * lanes_per_row*4 floats in its workgroup's LDS.  The entries of a workgroup's rows are sorted by (column popularity
+   * panel, slot, column popularity) and dealt in chunks of lanes_per_row entries to its sw_groups lane groups, round robin;
+   * lane group g of workgroup w walks its chunks as ONE contiguous stream [sw_gptr[w*sw_groups+g], sw_gptr[w*sw_groups+g+1])
+   * of sw_ent / sw_slot.  All lane groups resident on an XCD then sweep the dense operand from its most to its least
+   * referenced rows together, and a row fetched by one of them is served to the others by that XCD's L2.  Several lane
+   * groups add into one slot (LDS float adds), so the summation order of a swept row is not fixed run to run. */
   int32_t sw_rounds;        /* rounds per launch (0: no sweep) */
   int32_t sw_nwg;           /* workgroups per round = grid.x of the sweep launch */
   int32_t sw_groups;        /* lane groups per workgroup = 1024 / lanes_per_row */
-  int32_t sw_slots;         /* accumulator slots per workgroup = 8 * sw_groups */
-  const tgcn_edge* sw_ent;  /* [sw_gptr[last]] entries of the swept rows, col = column | unit << 28 */
+  int32_t sw_slots;         /* accumulator slots (rows) per workgroup = 8 * sw_groups */
+  const tgcn_edge* sw_ent;  /* [sw_gptr[last]] entries of the swept rows in stream order */
+  const int16_t* sw_slot;   /* [sw_gptr[last]] slot (row inside its workgroup) of every entry */
   const int32_t* sw_gptr;   /* [sw_rounds*sw_nwg*sw_groups + 1] */
-  const int32_t* sw_slot_row;   /* [sw_rounds*sw_nwg*sw_slots] row written from this slot (first unit of the row), or -1 */
-  const int32_t* sw_slot_chain; /* [sw_rounds*sw_nwg*sw_slots] offset into sw_chain of the row's other units, or -1 */
-  const int32_t* sw_chain;      /* per multi-unit row: count, then the slots of units 1..count in unit order */
+  const int32_t* sw_slot_row;   /* [sw_rounds*sw_nwg*sw_slots] row written from this slot, or -1 */
 } tgcn_csr_sched;
 
 /* Batched dense operand: element (b, i, c) lives at ptr[b*batch_stride + i*row_stride + c]. */
@@ -103,6 +101,32 @@ typedef struct tgcn_dense {
 
 const char* tgcn_last_error(void);
 int tgcn_abi_version(void);
+
+/* Operand and schedule construction inside the library (tgcn_graph_create_from_coo/csr, tgcn_graph_destroy),
+ * so that a caller of the C ABI needs nothing from the Python package.  These are the ONLY entry points that allocate
+ * device memory and synchronise (they copy the index arrays to the host, sort and scan there, and upload the result):
+ * call them once per graph, outside the forward path.  All index / value pointers are DEVICE pointers like everywhere else.
+ *   from_coo         entries in any order; duplicates of one (row, col) stay separate entries in their given order (their
+ *                    sum is what scatter_add computes, gcn.py:308,343)
+ *   from_csr         the same from row pointers (int64, rowptr[n] = nnz)
+ *   from_edge_index  the operand ChebConv / ChebTimeConv build on every forward (gcn.py:398-413 == :495-510) from the
+ *                    caller's (2, E) int64 edge list and optional weights: self loops removed, source-degree normalised
+ *   tgcn_sched_build the row-block + column-ordered-segment schedule of tgcn_csr_sched for rows of C floats (what
+ *                    tgcn_amd/graph.py::Schedule builds; the sweep schedule of very large operands is only built there) */
+typedef struct tgcn_graph tgcn_graph; /* opaque: owns its device arrays */
+typedef struct tgcn_sched tgcn_sched; /* opaque: owns its device arrays */
+int tgcn_graph_create_from_coo(int64_t n, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col, const float* val,
+                               tgcn_graph** out);
+int tgcn_graph_create_from_csr(int64_t n, int64_t n_cols, const int64_t* rowptr, const int32_t* col, const float* val,
+                               tgcn_graph** out);
+int tgcn_graph_create_from_edge_index(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_weight,
+                                      tgcn_graph** out);
+const tgcn_csr* tgcn_graph_csr(const tgcn_graph* g);
+int64_t tgcn_graph_n_cols(const tgcn_graph* g);
+void tgcn_graph_destroy(tgcn_graph* g);
+int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched** out);
+const tgcn_csr_sched* tgcn_sched_get(const tgcn_sched* s);
+void tgcn_sched_destroy(tgcn_sched* s);
 
 /* Optional launch timing for benchmarks: between start and stop every kernel launch made through this
  * library is bracketed by a hipEvent pair on its own stream.  stop() synchronises those events and returns
@@ -245,6 +269,11 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
 int tgcn_relu_pool_f32(void* stream, const float* x, float* out, uint8_t* idx, int64_t q, int64_t n, int32_t f, int32_t p);
 int tgcn_relu_pool_bwd_f32(void* stream, const float* grad_z, const float* z, const uint8_t* idx, float* grad_y, int64_t q,
                            int64_t n, int32_t f, int32_t p);
+
+/* Vertex sharding (replaces nn.DataParallel's batch split, examples/pytorch_based/pytorch_hcp_tgcn.py:270-273):
+ * out[i, 0:C] = src[idx[i], 0:C] -- the rows of a hop tensor that a neighbouring shard needs, packed into one message.
+ * idx: int64 device array; src rows ld_src floats apart; out contiguous. */
+int tgcn_pack_rows_f32(void* stream, const float* src, int64_t ld_src, const int64_t* idx, int64_t nrows, int32_t C, float* out);
 
 /* gcn_pool / gcn_pool_4 (gcn.py:246-255): max over p consecutive vertices; idx (nullable) receives the
  * arg-max offset 0..p-1 for the backward. */

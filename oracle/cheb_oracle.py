@@ -148,6 +148,29 @@ def cheb_time_conv_forward(x, edge_index, edge_weight, weight, bias):
     return out if bias is None else out + bias
 
 
+# ----------------------------------------------------------------------------- gradients (what autograd derives)
+def layer_backward(L, x, weight, grad_out, mode):
+    """Gradients of out = sum_k T_k(L) x W_k (+ bias) w.r.t. x and weight, in fp64: what torch autograd derives from the
+    forwards above (the examples train through them, examples/pytorch_based/pytorch_hcp_tgcn.py:167-169).  T_k is linear,
+    so  dW_k = (T_k x)^T g  and  dx = sum_k T_k(L^T) (g W_k^T).  mode "power": the dense-L classes' recursion
+    (stack_reference_power), "chebyshev": the edge-list classes' (stack_chebyshev).  x (q, n, *tail), weight (K, *tail, g).
+    Pinned by the grad_* arrays of tests/golden (tools/make_golden.py::grads)."""
+    stack = stack_reference_power if mode == "power" else stack_chebyshev
+    K, gch = weight.shape[0], weight.shape[-1]
+    q, n = x.shape[:2]
+    L64 = sp.csr_matrix(L, dtype=np.float64)
+    x64 = np.asarray(x, np.float64).reshape(q, n, -1)
+    W = np.asarray(weight, np.float64).reshape(K, -1, gch)
+    g = np.asarray(grad_out, np.float64)
+    Xt = stack(L64, x64, K)
+    gW = np.einsum("kqnt,qng->ktg", Xt, g, optimize=True).reshape(weight.shape)
+    LT = L64.T.tocsr()
+    gx = np.zeros_like(x64)
+    for k in range(K):
+        gx += stack(LT, g @ W[k].T, k + 1)[k]
+    return gx.reshape(x.shape), gW
+
+
 # ----------------------------------------------------------------------------- COO SpMM helpers
 def spmm(index, value, m, matrix):
     """tgcn/nn/gcn.py:258-278: out[r] += v_e * matrix[c] over the FIRST axis (1-D input is

@@ -49,6 +49,10 @@ def _hop(op, x, z, alpha, beta, out):
     return out
 
 
+def _pack(src, idx, out):
+    return out.copy_(src.index_select(0, idx))
+
+
 def _project(terms, W, bias, bias_kind, n_vertices):
     acc = sum(t.numpy().astype(np.float64) @ W[k].numpy().astype(np.float64) for k, t in enumerate(terms))
     if bias_kind == 1:
@@ -70,9 +74,14 @@ def _worker(rank, world, port, exchange, banded, mode, ret):
         W = (rng.standard_normal((K, C, N)) / 4).astype(np.float32)
         bias = rng.standard_normal((n, N)).astype(np.float32)
         sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), device="cpu",
-                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project)
-        out_local = sh.forward(torch.from_numpy(x[:, sh.lo:sh.hi]), torch.from_numpy(W),
-                               torch.from_numpy(bias[sh.lo:sh.hi]), 2, mode)
+                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project, pack_fn=_pack)
+        args = (torch.from_numpy(x[:, sh.lo:sh.hi]), torch.from_numpy(W), torch.from_numpy(bias[sh.lo:sh.hi]), 2, mode)
+        out_local = sh.forward(*args)                              # overlapped: interior rows / other time steps under the exchange
+        plain = sh.forward(*args, overlap=False)                   # one exchange, then one hop on all owned rows
+        assert torch.equal(out_local, plain), "overlapped and plain forms differ"
+        assert torch.equal(sh.forward(*args, depth=3), plain) and torch.equal(sh.forward(*args, depth=1), plain)
+        if sh.exchange == "halo" and banded:
+            assert 0 < sh.n_int < sh.owned                         # both classes of rows are exercised
         L = O.coo_to_csr(row, col, val, n)
         if mode == 1:
             basis = O.stack_chebyshev(L, x, K)
@@ -123,8 +132,9 @@ def _hybrid_worker(rank, world, port, exchange, banded, ret):
         group, gi, ng = hybrid_groups(world, 2)
         sl = shard_time_steps(q, gi, ng)                       # this group's samples
         sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), group=group, device="cpu",
-                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project)
+                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project, pack_fn=_pack)
         out_local = sh.forward(torch.from_numpy(x[sl, sh.lo:sh.hi]), torch.from_numpy(W), torch.from_numpy(bias), 1, 1)
+        assert torch.equal(out_local, sh.forward(torch.from_numpy(x[sl, sh.lo:sh.hi]), torch.from_numpy(W), torch.from_numpy(bias), 1, 1, overlap=False))
         L = O.coo_to_csr(row, col, val, n)
         ref = np.einsum("kqnc,kcg->qng", O.stack_chebyshev(L, x, K).astype(np.float64), W.astype(np.float64)) + bias
         err = np.abs(out_local.numpy() - ref[sl, sh.lo:sh.hi]).max() / np.abs(ref).max()

@@ -43,8 +43,11 @@ def _worker(rank, world, port, exchange, banded, ret):
         bias = rng.standard_normal((n, N)).astype(np.float32)
         dev = torch.device("cuda:0")
         sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), device=dev, exchange=exchange)
-        out = sh.forward(torch.as_tensor(x[:, sh.lo:sh.hi]).to(dev), torch.as_tensor(W).to(dev),
-                         torch.as_tensor(bias[sh.lo:sh.hi]).to(dev), 2, 1)
+        args = (torch.as_tensor(x[:, sh.lo:sh.hi]).to(dev), torch.as_tensor(W).to(dev), torch.as_tensor(bias[sh.lo:sh.hi]).to(dev), 2, 1)
+        out = sh.forward(*args)                                   # overlapped: HIP pack kernel, in-place receives, interior / boundary hops
+        assert torch.equal(out, sh.forward(*args, overlap=False)), "overlapped and plain forms differ"
+        if exchange == "halo":
+            assert 0 < sh.n_int < sh.owned
         L = O.coo_to_csr(row, col, val, n)
         ref = np.einsum("kqnc,kcg->qng", O.stack_chebyshev(L, x, K).astype(np.float64), W.astype(np.float64)) + bias
         err = np.abs(out.cpu().numpy() - ref[:, sh.lo:sh.hi]).max() / np.abs(ref).max()

@@ -30,6 +30,55 @@ def _dense_L(g):
 
 
 # ------------------------------------------------------------------------------------------ golden
+GRAD_TOL = 2e-5      # gradients of the reference modules' own autograd (tools/make_golden.py::grads), fp32
+
+
+def _make_layer(g):
+    """the module of a golden fixture with the reference's parameters, and the extra forward arguments"""
+    import tgcn_amd
+    kind = str(g["kind"])
+    bias = bool(g["has_bias"])
+    if kind in ("GCNCheb", "TGCNCheb"):
+        K, f, gg = g["weight"].shape
+        layer = getattr(tgcn_amd, kind)(_dense_L(g), f, gg, K, bias=bias)
+        extra = ()
+    elif kind == "TGCNCheb_H":
+        K, H, f, gg = g["weight"].shape
+        layer, extra = tgcn_amd.TGCNCheb_H(_dense_L(g), f, gg, K, H, bias=bias), ()
+    else:
+        w = _dev(g["edge_weight"]) if int(g["use_weight"]) else None
+        extra = (_dev(g["edge_index"]), w)
+        if kind == "ChebConv":
+            K, f, gg = g["weight"].shape
+            layer = tgcn_amd.ChebConv(f, gg, K, bias=bias)
+        else:
+            K, H, f, gg = g["weight"].shape
+            layer = tgcn_amd.ChebTimeConv(f, gg, K, H, bias=bias)
+    return _load_params(layer, g), extra
+
+
+_GRAD_FILES = [p for pre in ("GCNCheb_", "TGCNCheb_", "TGCNChebH_", "ChebConv_", "ChebTimeConv_") for p in golden_files(pre)]
+
+
+@pytest.mark.parametrize("small", [True, False], ids=["one-launch", "general"])
+@pytest.mark.parametrize("path", _GRAD_FILES, ids=golden_ids(_GRAD_FILES))
+def test_backward_golden(path, small, gpu_device, monkeypatch):
+    """x.grad / weight.grad / bias.grad against the reference modules' own autograd for the fixture's grad_output
+    (all five classes, K up to 25, the dense DTI graph, self loops, edge weights), on the LDS-resident path and on the
+    general hops + projection path."""
+    from tgcn_amd import functional as F
+    g = load_golden(path)
+    assert "grad_x" in g, "fixture without gradients: re-run tools/make_golden.py"
+    monkeypatch.setattr(F, "SMALL_PATH", small)
+    layer, extra = _make_layer(g)
+    x = _dev(g["x"]).requires_grad_(True)
+    out = layer(x, *extra)
+    assert rel_err(out.detach().cpu().numpy(), g["out"]) <= TOL
+    out.backward(_dev(g["grad_out"]))
+    assert rel_err(x.grad.cpu().numpy(), g["grad_x"]) <= GRAD_TOL
+    assert rel_err(layer.weight.grad.cpu().numpy(), g["grad_weight"]) <= GRAD_TOL
+    if int(g["has_bias"]):
+        assert rel_err(layer.bias.grad.cpu().numpy(), g["grad_bias"]) <= GRAD_TOL
 @pytest.mark.parametrize("path", golden_files("GCNCheb_"), ids=golden_ids(golden_files("GCNCheb_")))
 def test_gcncheb_golden(path, gpu_device):
     import tgcn_amd
@@ -51,7 +100,8 @@ def test_tgcncheb_golden(path, gpu_device):
     layer = _load_params(tgcn_amd.TGCNCheb(_dense_L(g), f, gg, K, bias=bool(g["has_bias"])), g)
     with torch.no_grad():
         assert rel_err(layer(_dev(g["x"])).cpu().numpy(), g["out"]) <= TOL
-        assert rel_err(layer._time_chebyshev(_dev(g["x"])).cpu().numpy(), g["stack"]) <= TOL
+        if g["stack"].size:
+            assert rel_err(layer._time_chebyshev(_dev(g["x"])).cpu().numpy(), g["stack"]) <= TOL
 
 
 @pytest.mark.parametrize("path", golden_files("TGCNChebH_"), ids=golden_ids(golden_files("TGCNChebH_")))
@@ -705,3 +755,63 @@ def test_hop_rectangular_operand(gpu_device):
     ref = np.stack([2.0 * L.dot(x[b].astype(np.float64)) - z[b] for b in range(3)])
     assert y.shape == (3, n, C)
     assert rel_err(y.cpu().numpy(), ref) <= TOL
+    # the transpose of a rectangular operand is n_cols x n (the input gradient of a vertex shard); .to() keeps the shape
+    opT = op.transpose()
+    assert (opT.n, opT.n_cols) == (ncols, n) and op.to("cuda").n_cols == ncols
+    g = rng.standard_normal((2, n, C)).astype(np.float32)
+    gt = F.csr_hop(opT, _dev(g))
+    assert rel_err(gt.cpu().numpy(), np.stack([L.T.dot(g[b].astype(np.float64)) for b in range(2)])) <= TOL
+
+
+def test_forward_accepts_a_misaligned_batch_slice(gpu_device):
+    """rows of 5 floats: data[i:i+bs] starts at a multiple of 4 bytes only; the reference takes any view (gcn.py:189-200)"""
+    import tgcn_amd
+    rng = np.random.default_rng(3)
+    n, C, K, g = 5001, 5, 4, 6
+    row, col, val = _random_graph(n, 7, rng, hubs=((3, 300),))
+    Lc = O.coo_to_csr(row, col, val, n)
+    op = tgcn_amd.GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    layer = tgcn_amd.GCNCheb(op, C, g, K).cuda()
+    data = torch.randn(4, n, C, device="cuda")
+    x = data[1:3]
+    assert x.data_ptr() % 16 != 0
+    with torch.no_grad():
+        out = layer(x)
+    ref = O.gcn_cheb_forward(Lc, x.cpu().numpy(), layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy())
+    assert rel_err(out.cpu().numpy(), ref) <= TOL
+
+
+def test_spmm_rectangular_and_pool_dtype(gpu_device):
+    """spmm* with more source rows than output rows (the reference's gather / scatter_add form allows it, gcn.py:296-308);
+    gcn_pool on a non-fp32 tensor"""
+    import tgcn_amd
+    rng = np.random.default_rng(4)
+    m, ns, E = 300, 700, 4000
+    idx = np.stack([rng.integers(0, m, E), rng.integers(0, ns, E)])
+    v = rng.standard_normal(E).astype(np.float32)
+    mat = rng.standard_normal((3, ns, 6)).astype(np.float32)
+    import scipy.sparse as sp
+    L = sp.coo_matrix((v.astype(np.float64), (idx[0], idx[1])), shape=(m, ns)).tocsr()
+    out = tgcn_amd.spmm_batch_2(_dev(idx), _dev(v), m, _dev(mat))
+    assert rel_err(out.cpu().numpy(), np.stack([L.dot(mat[b].astype(np.float64)) for b in range(3)])) <= TOL
+    out1 = tgcn_amd.spmm(_dev(idx), _dev(v), m, _dev(mat[0]))
+    assert rel_err(out1.cpu().numpy(), L.dot(mat[0].astype(np.float64))) <= TOL
+    xh = torch.randn(2, 16, 5, device="cuda").double()
+    assert torch.equal(tgcn_amd.gcn_pool_4(xh), xh.float().reshape(2, 4, 4, 5).max(dim=2)[0])
+
+
+def test_hop_batch_beyond_the_grid_limit(gpu_device):
+    """training forwards / spmm_batch_* hand the whole batch to one hop call: more than 65535 samples are sliced"""
+    from tgcn_amd import functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(5)
+    n, C, nb = 12, 4, 70000
+    row, col = rng.integers(0, n, 40), rng.integers(0, n, 40)
+    val = rng.standard_normal(40).astype(np.float32)
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    x = torch.randn(nb, n, C, device="cuda")
+    y = F.csr_hop(op, x)
+    Ld = torch.zeros(n, n, dtype=torch.float64)
+    Ld.index_put_((torch.as_tensor(row), torch.as_tensor(col)), torch.as_tensor(val).double(), accumulate=True)
+    ref = torch.einsum("nm,qmc->qnc", Ld.cuda(), x.double())
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) <= TOL

@@ -317,23 +317,33 @@ __global__ __launch_bounds__(kBlock) void hop_fixup_kernel(const HopParams p) {
 // --------------------------------------------------------------------------------------------------
 // sweep: long rows of large operands, accumulators in LDS, entries walked in order of column popularity
 // --------------------------------------------------------------------------------------------------
-// (include/tgcn_hip.h, tgcn_csr_sched ABI v3.)  One 1024-thread workgroup per CU; a lane group owns 8 accumulator slots in
-// LDS (lane t owns floats 4t..4t+3 of each: private words, no atomics, no barrier in the loop) and walks one contiguous
-// stream of entries sorted by (column popularity panel, unit, column popularity).  Consecutive entries of one unit are
-// summed in registers and added to the unit's slot when the unit changes.  Measured motive: on the 160 M-entry R-MAT the
-// column-ordered segments fetched 19.5 GB per launch for the rows above 32 entries, of which a trace-driven model of the
-// eight L2s (tools/sim) attributes 9 GB to rows of X re-fetched by workgroups that reach the same columns at different
-// times; with every resident workgroup sweeping the columns in the same order the model fetches 10.5 GB.
+// (include/tgcn_hip.h, tgcn_csr_sched ABI v3.)  One 1024-thread workgroup per CU holds the accumulators of up to
+// 8 * (1024 / lanes_per_row) rows in LDS.  The entries of those rows are sorted by (column popularity panel, row, column
+// popularity) and dealt to the lane groups in chunks of lanes_per_row entries, round robin: every lane group of every
+// resident workgroup is then in the same popularity panel at about the same time, so a row of X fetched by one of them is
+// served to the others by the XCD's L2.  (A first form that gave every lane group its own rows did not hold that lockstep:
+// 32 % L2 hits and 24 GB fetched per launch on the 160 M-entry R-MAT, against 47 % / 19.5 GB for the column-ordered
+// segments; tools/sim models both.)  Consecutive entries of one row are summed in registers and added to the row's slot
+// with no-return LDS float adds when the row changes: several lane groups add to one slot, so the order of those adds -- and
+// with it the last bits of the result -- is not fixed run to run (the reference's scatter_add on a GPU is no different,
+// gcn.py:308,343); the tests bound it by the 1e-5 parity tolerance.
 struct SweepParams {
   const tgcn_edge* ent;
+  const int16_t* slot;
   const int32_t* gptr;
   const int32_t* slot_row;
-  const int32_t* slot_chain;
-  const int32_t* chain;
   int32_t rounds, nwg;
 };
 
-constexpr int kSweepBlock = 1024, kSweepSlotsPerGroup = 8, kSweepUnitShift = 28, kSweepColMask = (1 << kSweepUnitShift) - 1;
+constexpr int kSweepBlock = 1024, kSweepSlotsPerGroup = 8;
+
+// word offset of channel word w of slot sl: rows of >= 64 words are rotated by 16 words per slot so that the four lane groups
+// of a wave, adding to four different slots, use different LDS banks
+template <int ROWF>
+__device__ __forceinline__ int sweep_word(int sl, int w) {
+  if constexpr (ROWF >= 64) return sl * ROWF + ((w + 16 * (sl & 3)) & (ROWF - 1));
+  else return sl * ROWF + w;
+}
 
 template <int LPR, int NTM, int UU>
 __global__ __launch_bounds__(kSweepBlock) void hop_sweep_kernel(const HopParams p, const SweepParams s) {
@@ -347,43 +357,49 @@ __global__ __launch_bounds__(kSweepBlock) void hop_sweep_kernel(const HopParams 
   const int c0 = t * VEC;
   const bool cact = c0 < p.C;
   const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
-  float* mine = sweep_acc + (g * SPG) * ROWF + c0;        // this lane's words of its group's 8 slots
   for (int round = 0; round < s.rounds; ++round) {
     const int wg = round * s.nwg + (int)blockIdx.x;
-#pragma unroll
-    for (int j = 0; j < SPG; ++j) *reinterpret_cast<float4*>(mine + j * ROWF) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < SLOTS * ROWF / 4; i += kSweepBlock) reinterpret_cast<float4*>(sweep_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     const int e0 = s.gptr[wg * G + g], e1 = s.gptr[wg * G + g + 1];
     float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
     int cur = 0;
+    auto flush = [&]() {   // no-return LDS float adds: nothing in the loop waits for them
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        (void)__hip_atomic_fetch_add(sweep_acc + sweep_word<ROWF>(cur, c0 + i), acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    int nx_c = 0, nx_s = 0;
+    float nx_v = 0.f;
+    if (e0 + t < e1) { load_edge<NTM>(s.ent, e0 + t, nx_c, nx_v); nx_s = s.slot[e0 + t]; }
     for (int e = e0; e < e1; e += LPR) {
-      int my_c = 0;
-      float my_v = 0.f;
-      if (e + t < e1) load_edge<NTM>(s.ent, e + t, my_c, my_v);
+      const int my_c = nx_c, my_s = nx_s;
+      const float my_v = nx_v;
+      nx_c = 0; nx_s = 0;
+      nx_v = 0.f;
+      if (e + LPR + t < e1) { load_edge<NTM>(s.ent, e + LPR + t, nx_c, nx_v); nx_s = s.slot[e + LPR + t]; }   // next chunk, under this chunk's gathers
       const int cnt = min(LPR, e1 - e);
 #pragma unroll
       for (int j0 = 0; j0 < LPR; j0 += U) {              // fully unrolled: the broadcast lane is an immediate
         if (j0 < cnt) {
           float xv[U][VEC];
           float vv[U];
-          int uu[U];
+          int ss[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int c = group_bcast<LPR>(my_c, j0 + u);
             vv[u] = __int_as_float(group_bcast<LPR>(__float_as_int(my_v), j0 + u));
-            uu[u] = (int)((unsigned)c >> kSweepUnitShift);
+            ss[u] = group_bcast<LPR>(my_s, j0 + u);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) xv[u][i] = 0.f;
-            if (j0 + u < cnt) load_vec<VEC>(Xc + (int64_t)(c & kSweepColMask) * p.x_ld, xv[u]);
+            if (j0 + u < cnt) load_vec<VEC>(Xc + (int64_t)c * p.x_ld, xv[u]);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if (j0 + u < cnt) {
-              if (uu[u] != cur) {                          // same for the lanes of a group: next unit of this group's stream
-                float4* sl = reinterpret_cast<float4*>(mine + cur * ROWF);
-                float4 o = *sl;
-                o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
-                *sl = o;
-                cur = uu[u];
+              if (ss[u] != cur) {                          // same for the lanes of a group: the next row of this chunk
+                flush();
+                cur = ss[u];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
               }
@@ -394,32 +410,18 @@ __global__ __launch_bounds__(kSweepBlock) void hop_sweep_kernel(const HopParams 
         }
       }
     }
-    {
-      float4* sl = reinterpret_cast<float4*>(mine + cur * ROWF);
-      float4 o = *sl;
-      o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
-      *sl = o;
-    }
+    flush();
     __syncthreads();
-    // fold the units of each row in unit order and write the row: the group that owns a row's first unit does it
+    // write the rows: lane group g takes slots g, g + G, ...
 #pragma unroll 1
     for (int j = 0; j < SPG; ++j) {
-      const int sl = g * SPG + j;
+      const int sl = j * G + g;
       const int row = s.slot_row[(int64_t)wg * SLOTS + sl];
       if (row < 0) continue;                               // same for the lanes of a group
       float a[VEC];
       {
-        const float4 o = *reinterpret_cast<const float4*>(sweep_acc + sl * ROWF + c0);
+        const float4 o = *reinterpret_cast<const float4*>(sweep_acc + sweep_word<ROWF>(sl, c0));
         a[0] = o.x; a[1] = o.y; a[2] = o.z; a[3] = o.w;
-      }
-      const int ch = s.slot_chain[(int64_t)wg * SLOTS + sl];
-      if (ch >= 0) {
-        const int n_more = s.chain[ch];
-        for (int i = 0; i < n_more; ++i) {
-          const int s2 = s.chain[ch + 1 + i];
-          const float4 o = *reinterpret_cast<const float4*>(sweep_acc + s2 * ROWF + c0);
-          a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w;
-        }
       }
       if (cact) finish_row<VEC, NTM>(p, b, row, c0, a);
     }

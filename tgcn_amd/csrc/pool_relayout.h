@@ -99,3 +99,14 @@ inline int grid_1d(int64_t total) {
   int64_t g = (total + kBlock - 1) / kBlock;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
+
+// out[i, :] = src[idx[i], :]: the rows a neighbouring vertex shard asked for, packed for one message (tgcn_amd/dist.py).
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ out, int64_t nrows, int32_t C, int64_t ld_src) {
+  const int64_t total = nrows * C;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    out[i] = src[idx[r] * ld_src + c];
+  }
+}

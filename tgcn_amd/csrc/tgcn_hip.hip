@@ -9,13 +9,19 @@
 //   wgrad.h          dW_t = A_t^T G, two deterministic stages on the fp32 MFMA
 //   small_graph.h    graphs that fit in LDS: whole layer / basis in ONE launch (sparse, first-layer, dense matrix-pipe)
 //   pool_relayout.h  (Q,n,C) -> (n,Q,C), gcn_pool / gcn_pool_4, relu + pool pass
+//   graph_build.h    tgcn_graph_* / tgcn_sched_*: operand and schedule construction inside the library (host code, one-off)
 // This file: the extern "C" entry points (argument checks, workspace carving, launches) declared in tgcn_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <math.h>
+
+#include <algorithm>
 #include <atomic>
+#include <new>
+#include <numeric>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -31,6 +37,7 @@ namespace {
 #include "wgrad.h"
 #include "small_graph.h"
 #include "pool_relayout.h"
+#include "graph_build.h"
 
 }  // namespace
 
@@ -117,10 +124,9 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
     if (g.vec != 4 || g.nchunks != 1 || g.lpr < 4) TGCN_FAIL(TGCN_ERR_INVALID, "hop: sweep schedule needs aligned rows of 16..256 floats (C=%d aligned16=%d)", C, al);
     if (S->sw_nwg <= 0 || S->sw_nwg > 65535 || S->sw_groups != kSweepBlock / g.lpr || S->sw_slots != kSweepSlotsPerGroup * S->sw_groups)
       TGCN_FAIL(TGCN_ERR_INVALID, "hop: sweep geometry %d workgroups x %d groups x %d slots does not fit %d lanes per row", S->sw_nwg, S->sw_groups, S->sw_slots, g.lpr);
-    if (!S->sw_ent || !S->sw_gptr || !S->sw_slot_row || !S->sw_slot_chain || !S->sw_chain) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null sweep arrays");
-    if (A->n >= (1 << kSweepUnitShift)) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: sweep schedule needs fewer than 2^28 columns");
+    if (!S->sw_ent || !S->sw_slot || !S->sw_gptr || !S->sw_slot_row) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null sweep arrays");
     if (nb > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: nb=%d > 65535 with a sweep schedule", nb);
-    sw.ent = S->sw_ent; sw.gptr = S->sw_gptr; sw.slot_row = S->sw_slot_row; sw.slot_chain = S->sw_slot_chain; sw.chain = S->sw_chain;
+    sw.ent = S->sw_ent; sw.slot = S->sw_slot; sw.gptr = S->sw_gptr; sw.slot_row = S->sw_slot_row;
     sw.rounds = S->sw_rounds; sw.nwg = S->sw_nwg;
   }
   if (S->npartial > 0) {
@@ -558,7 +564,8 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
   if (mode != 0 && mode != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward: mode %d", mode);
   if (layout != 0 && layout != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward: layout %d", layout);
   if (layout == 1 && (C > 32 || q * C > (int64_t)INT32_MAX)) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward: layout 1 needs C <= 32");
-  if (((uintptr_t)x & 15) || ((uintptr_t)workspace & 15)) TGCN_FAIL(TGCN_ERR_INVALID, "forward: x/workspace must be 16-byte aligned");
+  // rows of a multiple of 4 floats are read with 16-byte loads; other widths take the scalar forms and may start anywhere
+  if ((C % 4 == 0 && ((uintptr_t)x & 15)) || ((uintptr_t)workspace & 15)) TGCN_FAIL(TGCN_ERR_INVALID, "forward: x/workspace must be 16-byte aligned");
   const int64_t qc = (layout == 1 || q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
   size_t off_xt, off_hops, hop_bytes, off_part, total;
   fwd_ws_layout(S, K, q, n, C, layout, qc, &off_xt, &off_hops, &hop_bytes, &off_part, &total);
@@ -706,6 +713,14 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
       b1 = dst;
     }
   }
+  return TGCN_OK;
+}
+
+int tgcn_pack_rows_f32(void* stream, const float* src, int64_t ld_src, const int64_t* idx, int64_t nrows, int32_t C, float* out) {
+  if (!src || !idx || !out || nrows < 0 || C <= 0 || ld_src < C) TGCN_FAIL(TGCN_ERR_INVALID, "pack_rows: bad argument");
+  if (nrows == 0) return TGCN_OK;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_1d(nrows * C)), dim3(kBlock), 0, (hipStream_t)stream, src, idx, out, nrows, C, ld_src);
+  TGCN_CHECK_LAUNCH("tgcn_pack_rows_f32");
   return TGCN_OK;
 }
 

@@ -10,8 +10,13 @@ pytorch_hcp_tgcn.py:270-273).  The path shards two ways:
     owned row blocks when the halo is most of the graph (R-MAT);
   * both at once (`hybrid_groups`): vertex shards inside a group of ranks, time steps across groups.
 
+Vertex sharding overlaps communication with compute: a shard's rows are kept in the order
+[interior | boundary]; the interior rows of hop k (no remote column) run while the halo rows of hop k-1 are in flight,
+messages are packed by a HIP kernel and received in place, time steps are pipelined in groups of `depth` (the exchange
+of one under the hops of the others), and every buffer lives as long as the object.
+
 The compute callables are injectable so the communication logic is testable with gloo on CPU against the oracle
-(tests/test_dist_gloo.py); the defaults are the HIP entry points.
+(tests/test_dist_gloo.py: overlapped against non-overlapped form bit for bit); the defaults are the HIP entry points.
 """
 import torch
 import torch.distributed as dist
@@ -68,6 +73,12 @@ def _default_project(terms, W, bias, bias_kind, n_vertices):
     return F.cheb_project(terms, W, bias, bias_kind, n_vertices)
 
 
+def _default_pack(src, idx, out):
+    """out[i, :] = src[idx[i], :] -- the rows a peer asked for, packed for one message (HIP kernel tgcn_pack_rows_f32)"""
+    from . import functional as F
+    return F.pack_rows(src, idx, out)
+
+
 class VertexShardedCheb:
     """Vertex-sharded layer forward.  Every rank passes the same global COO of L-hat (or at least its own rows);
     rank r owns rows [bounds[r], bounds[r+1]).
@@ -79,13 +90,14 @@ class VertexShardedCheb:
     """
 
     def __init__(self, n, row, col, val, group=None, device=None, exchange="auto", make_operand=_default_operand,
-                 hop_fn=_default_hop, project_fn=_default_project):
+                 hop_fn=_default_hop, project_fn=_default_project, pack_fn=_default_pack):
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         # point-to-point peers are named by GLOBAL rank; inside a sub-group (hybrid layout) translate the group index
         self.peer = [dist.get_global_rank(group, p) if group is not None else p for p in range(self.world)]
         self.device = torch.device(device) if device is not None else row.device
-        self.hop_fn, self.project_fn = hop_fn, project_fn
+        self.hop_fn, self.project_fn, self.pack_fn = hop_fn, project_fn, pack_fn
+        self._bufs = {}
         row, col, val = row.to(self.device), col.to(self.device), val.to(self.device)
         self.n = n
         self.bounds = balanced_row_bounds(row, n, self.world)
@@ -124,64 +136,146 @@ class VertexShardedCheb:
             c_local = owner * self.n_max + (c - self.bounds[owner])
             self.n_ext = self.world * self.n_max
         self.op = make_operand(self.owned, self.n_ext, r, c_local, v, self.device)
+        # ---- overlapped form: owned rows in the order [interior | boundary] -- interior rows have no remote
+        # column, so their part of a hop runs while the exchange of the previous hop's cut rows is in flight
+        if exchange == "halo":
+            has_remote = torch.zeros(self.owned, dtype=torch.bool, device=self.device)
+            has_remote[r[remote]] = True
+            order = torch.argsort(has_remote.to(torch.int8), stable=True)          # interior rows first, original order inside each class
+            self.n_int = int((~has_remote).sum().item())
+        else:
+            order = torch.arange(self.owned, device=self.device)
+            self.n_int = 0                                                           # all-gather: the halo is (almost) everything
+        self.local_perm = order
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(self.owned, device=self.device)
+        self.local_inv = inv
+        r2 = inv[r]                                                                  # row in the [interior | boundary] order
+        if exchange == "halo":
+            c2 = torch.where(c_local < self.owned, inv[c_local.clamp(max=max(self.owned - 1, 0))], c_local)    # owned columns move with their rows
+            self.send_idx_l = [inv[idx] if idx.numel() else idx for idx in self.send_idx]
+        else:
+            c2 = c_local
+        is_int = r2 < self.n_int
+        self.op_int = make_operand(self.n_int, self.n_ext, r2[is_int], c2[is_int], v[is_int], self.device) if self.n_int else None
+        nb = self.owned - self.n_int
+        self.op_bnd = make_operand(nb, self.n_ext, r2[~is_int] - self.n_int, c2[~is_int], v[~is_int], self.device) if nb else None
+        # the same rows as one operand (non-overlapped form): identical labels, so both forms sum every row in the same order
+        self.op_all = make_operand(self.owned, self.n_ext, r2, c2, v, self.device) if exchange == "halo" else self.op
 
-    # ------------------------------------------------------------------ exchange
-    def _fill_ext(self, ext, p_owned):
-        """ext: (q, n_ext, C) buffer whose owned part already holds the previous hop; fetch the remote rows."""
-        q, _, C = ext.shape
+    # ------------------------------------------------------------------ layer, overlapped
+    def _buf(self, name, shape):
+        """buffers of the overlapped path live as long as the object (no allocation per hop)"""
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._bufs[name] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        return t
+
+    def _start_exchange(self, slot, k, src_ext):
+        """Start fetching the remote rows of hop tensor `src_ext` ((1, n_ext, C), owned part valid) into its own halo region;
+        returns the work handles.  Messages are packed by the pack kernel into per-peer send buffers and received IN PLACE."""
+        C = src_ext.shape[2]
         if self.exchange == "halo":
-            sends = [ext[:, idx, :].contiguous() if idx.numel() else None for idx in self.send_idx]
-            recvs = [torch.empty((q, cnt, C), dtype=ext.dtype, device=ext.device) if cnt else None for cnt in self.recv_counts]
             ops = []
-            for p in range(self.world):
-                if p == self.rank:
-                    continue
-                if recvs[p] is not None:
-                    ops.append(dist.P2POp(dist.irecv, recvs[p], self.peer[p], group=self.group))
-                if sends[p] is not None:
-                    ops.append(dist.P2POp(dist.isend, sends[p], self.peer[p], group=self.group))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
             off = self.owned
             for p in range(self.world):
-                if recvs[p] is not None:
-                    ext[:, off: off + self.recv_counts[p], :] = recvs[p]
-                    off += self.recv_counts[p]
-        else:
-            assert q == 1, "all-gather exchange runs one sample per pass"
-            mine = torch.zeros((self.n_max, C), dtype=ext.dtype, device=ext.device)
-            mine[: self.owned] = p_owned[0]
-            dist.all_gather_into_tensor(ext.view(self.world * self.n_max, C), mine, group=self.group)
+                cnt = self.recv_counts[p]
+                if p != self.rank and cnt:
+                    ops.append(dist.P2POp(dist.irecv, src_ext[0, off: off + cnt], self.peer[p], group=self.group))
+                off += cnt
+                idx = self.send_idx_l[p]
+                if p != self.rank and idx.numel():
+                    sb = self._buf(("send", slot, k & 1, p), (idx.numel(), C))
+                    self.pack_fn(src_ext[0], idx, sb)
+                    ops.append(dist.P2POp(dist.isend, sb, self.peer[p], group=self.group))
+            return dist.batch_isend_irecv(ops) if ops else []
+        raise AssertionError
 
-    def _owned_view(self, ext):
-        if self.exchange == "halo":
-            return ext[:, : self.owned, :]
-        return ext[:, self.rank * self.n_max: self.rank * self.n_max + self.owned, :]
-
-    # ------------------------------------------------------------------ layer
-    def forward(self, x_local, W, bias_local, bias_kind, mode):
+    def forward(self, x_local, W, bias_local, bias_kind, mode, overlap=True, depth=2):
         """x_local: (q, owned, C) rows of this shard; W: (K, C, N) (already monomial-folded for mode 0);
-        bias_local: per channel [N] or this shard's rows [owned, N].  Returns out_local (q, owned, N)."""
+        bias_local: per channel [N] or this shard's rows [owned, N].  Returns out_local (q, owned, N).
+        overlap=True: the exchange of hop k runs under the interior rows of the same hop and under the hops of the other
+        time steps of a group of `depth` (per-time-step pipelining); same arithmetic row by row as overlap=False."""
+        if not overlap:
+            return self.forward_simple(x_local, W, bias_local, bias_kind, mode)
         q, owned, C = x_local.shape
         assert owned == self.owned
         K, _, N = W.shape
+        ni = self.n_int
         out = torch.empty((q, owned, N), dtype=torch.float32, device=x_local.device)
-        step = q if self.exchange == "halo" else 1
-        for q0 in range(0, q, step):
-            xs = x_local[q0: q0 + step].contiguous()
-            terms = [xs]
+        allg = self.exchange != "halo"
+        bias_l = bias_local
+        if bias_kind == 2 and bias_local is not None and not allg:
+            bias_l = bias_local.index_select(0, self.local_perm)
+        for t0 in range(0, q, depth):
+            steps = range(t0, min(q, t0 + depth))
+            # hop tensors of a time step: K buffers of (1, n_ext, C) [halo] or (n_max, C) + one gathered copy [all-gather]
+            if allg:
+                mine = {s: [self._buf(("mine", s - t0, k), (self.n_max, C)) for k in range(K)] for s in steps}
+                ext = {s: self._buf(("ext", s - t0), (1, self.n_ext, C)) for s in steps}
+                for s in steps:
+                    mine[s][0][: owned].copy_(x_local[s])
+                    mine[s][0][owned:].zero_()
+                own = lambda s, k: mine[s][k][: owned].unsqueeze(0)
+            else:
+                exts = {s: [self._buf(("ext", s - t0, k), (1, self.n_ext, C)) for k in range(K)] for s in steps}
+                for s in steps:
+                    exts[s][0][0, : owned].copy_(x_local[s].index_select(0, self.local_perm))
+                own = lambda s, k: exts[s][k][:, : owned]
             for k in range(1, K):
-                ext = torch.empty((step, self.n_ext, C), dtype=torch.float32, device=xs.device)
-                if self.exchange == "halo":
-                    ext[:, : self.owned] = terms[k - 1]
-                self._fill_ext(ext, terms[k - 1])
-                y = torch.empty((step, owned, C), dtype=torch.float32, device=xs.device)
-                if mode == 0 or k == 1:
-                    self.hop_fn(self.op, ext, None, 1.0, 0.0, y)
+                works = {}
+                for s in steps:                                       # 1. start every exchange of this hop level
+                    if allg:
+                        works[s] = [dist.all_gather_into_tensor(ext[s].view(self.world * self.n_max, C), mine[s][k - 1], group=self.group, async_op=True)]
+                    else:
+                        works[s] = self._start_exchange(s - t0, k, exts[s][k - 1])
+                if not allg and ni:
+                    for s in steps:                                   # 2. interior rows: no remote column, no wait
+                        z = own(s, k - 2)[:, : ni] if (mode != 0 and k >= 2) else None
+                        self.hop_fn(self.op_int, exts[s][k - 1], z, 2.0 if z is not None else 1.0, -1.0 if z is not None else 0.0, own(s, k)[:, : ni])
+                for s in steps:                                       # 3. boundary rows as their halo arrives
+                    for w in works[s]:
+                        w.wait()
+                    src = ext[s] if allg else exts[s][k - 1]
+                    opb = self.op if allg else self.op_bnd
+                    if opb is not None:
+                        z = own(s, k - 2)[:, ni:] if (mode != 0 and k >= 2) else None
+                        self.hop_fn(opb, src, z, 2.0 if z is not None else 1.0, -1.0 if z is not None else 0.0, own(s, k)[:, ni:])
+            for s in steps:
+                o = self.project_fn([own(s, k).reshape(owned, C) for k in range(K)], W, bias_l, bias_kind, owned)
+                o = o.reshape(owned, N)
+                out[s] = o if allg else o.index_select(0, self.local_inv)
+        return out
+
+    # ------------------------------------------------------------------ layer, one exchange after the other
+    def forward_simple(self, x_local, W, bias_local, bias_kind, mode):
+        """The same layer without overlap: blocking exchange, then the hop on all owned rows (what the overlapped form is
+        tested against, bit for bit: same operand labels, same order of every row's sum)."""
+        q, owned, C = x_local.shape
+        assert owned == self.owned
+        K, _, N = W.shape
+        halo = self.exchange == "halo"
+        out = torch.empty((q, owned, N), dtype=torch.float32, device=x_local.device)
+        bias_l = bias_local
+        if halo and bias_kind == 2 and bias_local is not None:
+            bias_l = bias_local.index_select(0, self.local_perm)
+        for s in range(q):
+            xs = x_local[s].index_select(0, self.local_perm) if halo else x_local[s]
+            terms = [xs.unsqueeze(0)]
+            for k in range(1, K):
+                ext = torch.empty((1, self.n_ext, C), dtype=torch.float32, device=xs.device)
+                if halo:
+                    ext[0, : owned] = terms[k - 1][0]
+                    for w in self._start_exchange(0, k, ext):
+                        w.wait()
                 else:
-                    self.hop_fn(self.op, ext, terms[k - 2], 2.0, -1.0, y)
+                    mine = torch.zeros((self.n_max, C), dtype=torch.float32, device=xs.device)
+                    mine[: owned] = terms[k - 1][0]
+                    dist.all_gather_into_tensor(ext.view(self.world * self.n_max, C), mine, group=self.group)
+                y = torch.empty((1, owned, C), dtype=torch.float32, device=xs.device)
+                z = terms[k - 2] if (mode != 0 and k >= 2) else None
+                self.hop_fn(self.op_all, ext, z, 2.0 if z is not None else 1.0, -1.0 if z is not None else 0.0, y)
                 terms.append(y)
-            o = self.project_fn([t.reshape(step * owned, C) for t in terms], W, bias_local, bias_kind, owned)
-            out[q0: q0 + step] = o.reshape(step, owned, N)
+            o = self.project_fn([t.reshape(owned, C) for t in terms], W, bias_l, bias_kind, owned).reshape(owned, N)
+            out[s] = o.index_select(0, self.local_inv) if halo else o
         return out

@@ -43,6 +43,14 @@ def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=No
         assert t is None or tuple(t.shape) == (nb, op.n, Crow), (t.shape, (nb, op.n, Crow))
     al = _aligned16(Crow, x, z, y, p, z2)
     sched = op.schedule_for(Crow, al)
+    # the batch rides on grid.y (x column chunks of wide rows): slice batches beyond its 65535 limit
+    nb_max = 65535 // max(1, -(-Crow // (256 if al else 64)))
+    if nb > nb_max:
+        for b0 in range(0, nb, nb_max):
+            sl = slice(b0, min(nb, b0 + nb_max))
+            csr_hop(op, x[sl], None if z is None else z[sl], alpha, beta, want_p, y[sl], None if p is None else p[sl],
+                    None if z2 is None else z2[sl], gamma)
+        return (y, p) if want_p else y
     ws_bytes = L.tgcn_csr_hop_workspace_bytes(C.byref(sched.struct), nb, Crow, 1 if al else 0)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     X, Y = _dense(x), _dense(y)
@@ -145,6 +153,8 @@ def cheb_forward_raw(op, x3, Wt, bias, bias_kind, mode, K, layout=None, q_chunk=
     q, n, Crow = x3.shape
     N = Wt.shape[1]
     assert x3.is_contiguous() and Wt.is_contiguous() and Wt.shape[0] == K * Crow and n == op.n
+    if x3.data_ptr() % 16:          # a batch slice data[i:i+bs] of odd-width rows may start at any float: the driver wants 16 bytes
+        x3 = x3.clone()
     if layout is None:
         layout = choose_layout(q, n, Crow)
     if q_chunk is None:
@@ -164,6 +174,13 @@ def cheb_stack(op, x3, K, mode):
     """The (K, q, n, C) stack `_chebyshev` / `_time_chebyshev` return (gcn.py:52-79,126-154,208-237), or the
     true-recurrence stack for mode 1.  Materialising path: every hop writes its slice of the stack."""
     _lib.require_device(x3)
+    if op.perm is not None:
+        perm, inv = op.perm, op.inv_perm
+        op.perm = None
+        try:
+            return cheb_stack(op, x3.index_select(1, perm), K, mode).index_select(2, inv)
+        finally:
+            op.perm = perm
     q, n, Crow = x3.shape
     st = torch.empty((K, q, n, Crow), dtype=torch.float32, device=x3.device)
     st[0].copy_(x3)
@@ -369,10 +386,23 @@ def _pad_rows(op, x3, weight_kcn, mode):
     return torch.nn.functional.pad(x3, (0, pad)), torch.nn.functional.pad(weight_kcn, (0, 0, 0, pad))
 
 
+def _to_operand_labels(op, x3, bias, bias_kind):
+    """A reordered operand (GraphOperand.reordered) works in its own vertex labels: gather the rows of x and of a per-vertex
+    bias into them (differentiable torch index ops: plumbing, no arithmetic)."""
+    if op.perm is None:
+        return x3, bias
+    x3 = x3.index_select(1, op.perm)
+    if bias is not None and bias_kind == BIAS_VERTEX_CHANNEL:
+        bias = bias.reshape(op.n, -1).index_select(0, op.perm)
+    return x3, bias
+
+
 def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode):
     """Differentiable fused layer; weight_kcn: (K, C, N) in the reference basis."""
     x3, weight_kcn = _pad_rows(op, x3, weight_kcn, mode)
-    return ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind)
+    x3, bias = _to_operand_labels(op, x3, bias, bias_kind)
+    out = ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind)
+    return out if op.perm is None else out.index_select(1, op.inv_perm)
 
 
 def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis=None):
@@ -479,7 +509,19 @@ class ChebReluPoolFn(torch.autograd.Function):
 def cheb_relu_pool(op, x3, weight_kcn, bias, bias_kind, mode, pool):
     """Differentiable relu + max-pool fused layer; weight in the reference basis."""
     x3, weight_kcn = _pad_rows(op, x3, weight_kcn, mode)
+    if op.perm is not None:     # pooling groups consecutive vertices of the CALLER's labelling: relabel back before the pool
+        y = torch.relu(cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode))
+        return PoolMaxFn.apply(y, pool)
     return ChebReluPoolFn.apply(x3, weight_kcn, bias, op, mode, bias_kind, pool)
+
+
+def pack_rows(src, idx, out):
+    """out[i] = src[idx[i]] for a (rows, C) view with contiguous rows (halo messages of the vertex-sharded layer)"""
+    _lib.require_device(src, idx, out)
+    assert src.dim() == 2 and src.stride(1) == 1 and out.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+    _lib.check(_lib.lib().tgcn_pack_rows_f32(_lib.stream_ptr(), _lib.ptr(src), src.stride(0), _lib.ptr(idx), idx.numel(), src.shape[1],
+                                             _lib.ptr(out)))
+    return out
 
 
 # ----------------------------------------------------------------------------------------- pooling
@@ -487,7 +529,7 @@ class PoolMaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p):
         _lib.require_device(x)
-        x = x.contiguous()
+        x = x.float().contiguous()       # the kernel reads fp32; the reference's torch.max takes any dtype (gcn.py:246-255)
         q, n, f = x.shape
         out = torch.empty((q, n // p, f), dtype=torch.float32, device=x.device)
         idx = torch.empty((q, n // p, f), dtype=torch.int32, device=x.device)

@@ -19,10 +19,10 @@ MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather tha
 # sweep schedule of the long rows (include/tgcn_hip.h, tgcn_csr_sched ABI v3; kernel: csrc/hop.h hop_sweep_kernel)
 SWEEP = True                    # developer switch
 SWEEP_MIN_ENTRIES = 8_000_000   # entries in rows above ROW_THRESH from which the sweep replaces the segments (smaller operands sit in L2 / the Infinity Cache anyway)
-SWEEP_UNIT = 1024               # entries per unit: longer rows are cut so that the lane groups of a workgroup stay balanced
 SWEEP_WORKGROUPS = 256          # persistent workgroups per round: one per CU of an MI355X
 SWEEP_PANEL_BYTES = 2 << 20     # rows of X per popularity panel = this / row bytes: half of one XCD's L2
 SWEEP_SLOTS_PER_GROUP = 8
+SWEEP_HOT_PANELS = 64           # popularity panels that are swept one by one; the columns behind them are ONE panel (a unit's cold entries form one run)
 
 
 def _as_i32(t):
@@ -111,131 +111,84 @@ class Schedule:
                                        self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
                                        self.long_slot.data_ptr(),
                                        sw.rounds if sw else 0, sw.nwg if sw else 0, sw.groups if sw else 0, sw.slots if sw else 0,
-                                       sw.ent.data_ptr() if sw else None, sw.gptr.data_ptr() if sw else None,
-                                       sw.slot_row.data_ptr() if sw else None, sw.slot_chain.data_ptr() if sw else None,
-                                       sw.chain.data_ptr() if sw else None)
+                                       sw.ent.data_ptr() if sw else None, sw.slot.data_ptr() if sw else None,
+                                       sw.gptr.data_ptr() if sw else None, sw.slot_row.data_ptr() if sw else None)
 
 
 class SweepSchedule:
-    """Sweep schedule of the rows above the row threshold (tgcn_csr_sched ABI v3, include/tgcn_hip.h): which workgroup,
-    lane group and accumulator slot every (row, unit) gets, and the entries of every lane group as one stream in order of
-    (column popularity panel, unit, column popularity).  Index plumbing on torch tensors, any device."""
+    """Sweep schedule of the rows above the row threshold (tgcn_csr_sched ABI v3, include/tgcn_hip.h): which workgroup and
+    accumulator slot every row gets, and the entries of every lane group as one stream -- the workgroup's entries in order
+    of (column popularity panel, slot, column popularity), dealt to its lane groups in chunks of lanes_per_row, round robin.
+    Index plumbing on torch tensors, any device."""
 
     @staticmethod
-    def build(rowptr, edges, n, n_cols, lanes_per_row, row_thresh, nwg=None, unit=None, panel_rows=None, force=False):
+    def build(rowptr, edges, n, n_cols, lanes_per_row, row_thresh, nwg=None, panel_rows=None, force=False):
         dev = rowptr.device
         deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
         rows = (deg > row_thresh).nonzero().flatten()
-        if rows.numel() == 0 or n_cols >= (1 << 28) or lanes_per_row < 4:
+        if rows.numel() == 0 or lanes_per_row < 4:
             return None
         if not force and (not SWEEP or int(deg[rows].sum().item()) < SWEEP_MIN_ENTRIES):
             return None
         nwg = SWEEP_WORKGROUPS if nwg is None else nwg
-        unit = SWEEP_UNIT if unit is None else unit
         G = 1024 // lanes_per_row
-        spg = SWEEP_SLOTS_PER_GROUP
-        slots = spg * G
+        slots = SWEEP_SLOTS_PER_GROUP * G
         P = max(1, SWEEP_PANEL_BYTES // (lanes_per_row * 16)) if panel_rows is None else panel_rows
         self = SweepSchedule()
-        # rows by decreasing length; k units per row
+        # rows by decreasing length, dealt to the workgroups of a round in snake order: every workgroup gets the same mix
         order = torch.argsort(deg[rows], descending=True, stable=True)
         rows = rows[order]
         dl = deg[rows]
         nL = rows.numel()
-        k = ((dl + unit - 1) // unit).clamp_(1, slots // 2)
-        cu = torch.cumsum(k, 0) - k
         ar = torch.arange(nL, device=dev, dtype=torch.int64)
-        fill = 0.97
-        while True:
-            cap = max(int(nwg * slots * fill), 1)
-            rnd = cu // cap
-            R = int(rnd[-1].item()) + 1
-            first = torch.searchsorted(rnd, torch.arange(R, device=dev, dtype=torch.int64))
-            idx = ar - first[rnd]
-            pos = idx % (2 * nwg)
-            wg = torch.where(pos < nwg, pos, 2 * nwg - 1 - pos)        # snake: every workgroup gets the same mix of row lengths
-            wgid = rnd * nwg + wg
-            used = torch.zeros(R * nwg, dtype=torch.int64, device=dev).index_add_(0, wgid, k)
-            if int(used.max().item()) <= slots:
-                break
-            fill *= 0.9
-            if fill < 0.05:
-                return None
-        # units: (row, residue); unit u of row i holds the entries p = u, u + k, u + 2k, ...
-        nU = int(k.sum().item())
-        u_row = torch.repeat_interleave(ar, k)
-        u_res = torch.arange(nU, device=dev, dtype=torch.int64) - cu[u_row]
-        u_len = (dl[u_row] - u_res + k[u_row] - 1) // k[u_row]
-        u_wg = wgid[u_row]
-        # inside a workgroup: units by decreasing length, dealt to the lane groups in snake order, 8 per group at most
-        maxlen = int(u_len.max().item()) + 1
-        uo = torch.argsort(u_wg * maxlen + (maxlen - 1 - u_len), stable=True)
-        wg_sorted = u_wg[uo]
-        wfirst = torch.searchsorted(wg_sorted, torch.arange(R * nwg, device=dev, dtype=torch.int64))
-        uidx = torch.arange(nU, device=dev, dtype=torch.int64) - wfirst[wg_sorted]
-        j_s = uidx // G
-        gpos = uidx % G
-        g_s = torch.where(j_s % 2 == 0, gpos, G - 1 - gpos)
-        u_j = torch.empty(nU, dtype=torch.int64, device=dev)
-        u_g = torch.empty(nU, dtype=torch.int64, device=dev)
-        u_j[uo] = j_s
-        u_g[uo] = g_s
-        assert int(u_j.max().item()) < spg
-        u_slot = u_g * spg + u_j                                   # slot inside the workgroup
-        # slot tables
+        per_round = nwg * slots
+        R = -(-nL // per_round)
+        rnd = ar // per_round
+        idx = ar - rnd * per_round
+        pos = idx % (2 * nwg)
+        wg = torch.where(pos < nwg, pos, 2 * nwg - 1 - pos)
+        r_wg = rnd * nwg + wg
+        r_slot = 2 * (idx // (2 * nwg)) + (pos >= nwg).to(torch.int64)
         self.slot_row = torch.full((R * nwg * slots,), -1, dtype=torch.int32, device=dev)
-        self.slot_chain = torch.full((R * nwg * slots,), -1, dtype=torch.int32, device=dev)
-        head = u_res == 0
-        self.slot_row[(u_wg * slots + u_slot)[head]] = rows[u_row[head]].to(torch.int32)
-        multi = k > 1
-        if bool(multi.any()):
-            km = k[multi]
-            coff = torch.cumsum(km, 0) - km                        # per multi-unit row: 1 count + (k-1) slots = k ints
-            chain = torch.empty(int(km.sum().item()), dtype=torch.int32, device=dev)
-            chain[coff] = (km - 1).to(torch.int32)
-            row_coff = torch.full((nL,), -1, dtype=torch.int64, device=dev)
-            row_coff[multi] = coff
-            tail = (u_res > 0)
-            chain[(row_coff[u_row] + u_res)[tail]] = u_slot[tail].to(torch.int32)
-            hm = head & multi[u_row]
-            self.slot_chain[(u_wg * slots + u_slot)[hm]] = row_coff[u_row[hm]].to(torch.int32)
-            self.chain = chain
-        else:
-            self.chain = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.slot_row[r_wg * slots + r_slot] = rows.to(torch.int32)
         # entries of the swept rows
-        starts = rowptr[rows].to(torch.int64)
-        e_rowl = torch.repeat_interleave(ar, dl)
         nE = int(dl.sum().item())
-        e_pos = torch.arange(nE, device=dev, dtype=torch.int64) - torch.repeat_interleave(torch.cumsum(dl, 0) - dl, dl)
-        e_idx = starts[e_rowl] + e_pos
-        e_unit = cu[e_rowl] + e_pos % k[e_rowl]
-        del e_pos, e_rowl
-        col = edges[: , 0][e_idx].to(torch.int64)
+        e_rowl = torch.repeat_interleave(ar, dl)
+        e_idx = rowptr[rows].to(torch.int64)[e_rowl] + (torch.arange(nE, device=dev, dtype=torch.int64) - torch.repeat_interleave(torch.cumsum(dl, 0) - dl, dl))
+        col = edges[:, 0][e_idx].to(torch.int64)
         cnt = torch.bincount(edges[: max(int(rowptr[-1].item()), 1), 0].to(torch.int64), minlength=n_cols)
         corder = torch.argsort(cnt, descending=True, stable=True)
         crank = torch.empty(n_cols, dtype=torch.int64, device=dev)
         crank[corder] = torch.arange(n_cols, device=dev, dtype=torch.int64)
         del cnt, corder
         cr = crank[col]
-        del crank
-        npan = (n_cols + P - 1) // P + 1
-        stream = u_wg[e_unit] * G + u_g[e_unit]
-        key = (stream * npan + cr // P) * spg + u_j[e_unit]
+        del crank, col
+        e_wg = r_wg[e_rowl]
+        e_slot = r_slot[e_rowl]
+        del e_rowl
+        # order inside a workgroup: (panel, slot, popularity); the columns behind the hot panels are one panel
+        npan = SWEEP_HOT_PANELS + 2
+        key = (e_wg * npan + torch.clamp(cr // P, max=SWEEP_HOT_PANELS)) * slots + e_slot
         o1 = torch.argsort(cr, stable=True)
-        o2 = torch.argsort(key[o1], stable=True)
-        o = o1[o2]
-        del o1, o2, cr, key
-        ent = torch.empty((max(nE, 1), 2), dtype=torch.int32, device=dev)
-        packed = col[o] | (u_j[e_unit[o]] << 28)
-        ent[:nE, 0] = packed.to(torch.int32) if packed.numel() == 0 else torch.where(packed >= (1 << 31), packed - (1 << 32), packed).to(torch.int32)
-        ent[:nE, 1] = edges[:, 1][e_idx[o]]
-        self.ent = ent
+        o = o1[torch.argsort(key[o1], stable=True)]
+        del o1, key, cr
+        wg_s = e_wg[o]
+        per_wg = torch.bincount(e_wg, minlength=R * nwg)
+        wfirst = torch.cumsum(per_wg, 0) - per_wg
+        chunk = (torch.arange(nE, device=dev, dtype=torch.int64) - wfirst[wg_s]) // lanes_per_row
+        stream = wg_s * G + chunk % G                      # chunks of lanes_per_row entries, round robin over the lane groups
+        del chunk, wg_s
+        o2 = torch.argsort(stream, stable=True)
         per_stream = torch.bincount(stream, minlength=R * nwg * G)
+        o = o[o2]
+        del o2, stream
+        self.ent = edges[e_idx[o]].contiguous() if nE else torch.zeros((1, 2), dtype=torch.int32, device=dev)
+        self.slot = e_slot[o].to(torch.int16).contiguous() if nE else torch.zeros(1, dtype=torch.int16, device=dev)
         gptr = torch.zeros(R * nwg * G + 1, dtype=torch.int64, device=dev)
         torch.cumsum(per_stream, 0, out=gptr[1:])
         self.gptr = _as_i32(gptr)
         self.rounds, self.nwg, self.groups, self.slots = R, nwg, G, slots
-        self.n_rows, self.n_entries, self.n_units, self.panel_rows = nL, nE, nU, P
+        self.n_rows, self.n_entries, self.panel_rows = nL, nE, P
         return self
 
 
@@ -266,10 +219,38 @@ class GraphOperand:
                                      self.dense.data_ptr() if self.dense is not None else None)
         self._sched = {}
         self._transpose = None
+        self.perm = None          # reordered(): internal row i holds the caller's vertex perm[i]
+        self.inv_perm = None
+
+    # ------------------------------------------------------------------ vertex reordering
+    def reordered(self, kind):
+        """The same operator with its vertices relabelled for locality -- P L P^T plus the permutation, which the layer
+        functions apply to x / bias on the way in and to the result on the way out (functional.cheb_layer), so callers keep
+        their own labels.  "degree": decreasing number of stored entries (hubs first); "rcm": reverse Cuthill-McKee of the
+        symmetrised pattern (scipy, on the host, one-off) -- the bandwidth-reducing order the reference's coarsened graphs
+        get from their construction (gcn/coarsening.py:167-217 orders vertices by cluster).  Square operands only."""
+        assert self.n == self.n_cols, "reordered(): square operands only"
+        row, col, val = self.coo()
+        if kind == "degree":
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+            perm = torch.argsort(deg, descending=True, stable=True)
+        elif kind == "rcm":
+            import scipy.sparse as sp
+            from scipy.sparse.csgraph import reverse_cuthill_mckee
+            r, c = row.cpu().numpy(), col.cpu().numpy()
+            pat = sp.coo_matrix((torch.ones(r.shape[0]).numpy(), (r, c)), shape=(self.n, self.n)).tocsr()
+            perm = torch.as_tensor(reverse_cuthill_mckee((pat + pat.T).tocsr(), symmetric_mode=True).astype("int64"), device=self.device)
+        else:
+            raise _lib.TgcnError("reordered(): unknown order %r (degree | rcm)" % (kind,))
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(self.n, device=self.device)
+        op = GraphOperand.from_coo(self.n, inv[row], inv[col], val, self.device)
+        op.perm, op.inv_perm = perm, inv
+        return op
 
     @property
     def shape(self):
-        return (self.n, self.n)
+        return (self.n, self.n_cols)
 
     # ------------------------------------------------------------------ constructors
     @staticmethod
@@ -374,13 +355,14 @@ class GraphOperand:
         ChebConv normalises by the source degree only, so the general case is kept)."""
         if self._transpose is None:
             row, col, val = self.coo()
-            self._transpose = GraphOperand.from_coo(self.n, col, row, val, self.device)
+            # a rectangular operand (vertex shard: n owned rows x n_cols owned + halo columns) transposes to n_cols x n
+            self._transpose = GraphOperand.from_coo(self.n_cols, col, row, val, self.device, n_cols=self.n)
             self._transpose._transpose = self
         return self._transpose
 
     def to(self, device):
         row, col, val = self.coo()
-        return GraphOperand.from_coo(self.n, row, col, val, device)
+        return GraphOperand.from_coo(self.n, row, col, val, device, n_cols=self.n_cols)
 
     def schedule(self, lanes_per_row, sweep=False):
         """sweep: the caller's rows are 16-byte aligned and fit one lane group (<= 256 floats), so the long rows may go on the

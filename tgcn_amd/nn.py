@@ -210,15 +210,18 @@ class GCNCheb(_DenseLBase):
 _spmm_ops = _OperandCache()
 
 
-def _coo_operand(index, value, m, device):
-    key = (_tensor_key(index), _tensor_key(value), int(m), str(device))
-    return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value, device), sources=(index, value))
+def _coo_operand(index, value, m, device, n_cols=None):
+    """m x n_cols operand: the reference's gather / scatter_add form takes any number of source rows (gcn.py:296-308)."""
+    n_cols = int(m if n_cols is None else n_cols)
+    key = (_tensor_key(index), _tensor_key(value), int(m), n_cols, str(device))
+    return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value, device, n_cols=n_cols),
+                         sources=(index, value))
 
 
 def spmm(index, value, m, matrix):
     """out[r] += v_e * matrix[c] over axis 0 (reference: gcn.py:258-278)."""
     matrix = matrix if matrix.dim() > 1 else matrix.unsqueeze(-1)
-    op = _coo_operand(index, value, m, matrix.device)
+    op = _coo_operand(index, value, m, matrix.device, matrix.shape[0])
     x3 = matrix.float().reshape(1, matrix.shape[0], -1).contiguous()
     return F.csr_hop(op, x3).reshape((m,) + tuple(matrix.shape[1:]))
 
@@ -232,7 +235,7 @@ def spmm_batch_2(index, value, m, matrix):
 
 def spmm_batch_3(index, value, m, matrix):
     """Same product over axis 1 of (q, n, h, f) (reference: gcn.py:313-345)."""
-    op = _coo_operand(index, value, m, matrix.device)
+    op = _coo_operand(index, value, m, matrix.device, matrix.shape[1])
     sh = matrix.shape
     x3 = matrix.float().reshape(sh[0], sh[1], -1).contiguous()
     return F.csr_hop(op, x3).reshape((sh[0], m) + tuple(sh[2:]))

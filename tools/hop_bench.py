@@ -29,8 +29,9 @@ def main():
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
     ap.add_argument("--sweep", default="1", help="comma list of 0/1: long rows on the sweep schedule (1) or as column-ordered segments (0)")
     ap.add_argument("--sweep-loads", default="8", help="comma list: row loads in flight per lane of the sweep kernel (4, 8, 16)")
-    ap.add_argument("--sweep-unit", type=int, default=None)
     ap.add_argument("--sweep-panel-kb", type=int, default=None)
+    ap.add_argument("--sweep-hot-panels", type=int, default=None)
+    ap.add_argument("--sweep-thresh", type=int, default=None, help="rows above this many entries go on the sweep schedule (ROW_THRESH)")
     args = ap.parse_args()
     from tools import synth
     from tgcn_amd import _lib, graph, functional as F
@@ -50,8 +51,10 @@ def main():
         keep = (deg[row] > thr) if args.only == "long" else (deg[row] <= thr)
         row, col, val = row[keep], col[keep], val[keep]
         print("kept %d entries (%s rows)" % (row.numel(), args.only), flush=True)
-    if args.sweep_unit:
-        graph.SWEEP_UNIT = args.sweep_unit
+    if args.sweep_hot_panels is not None:
+        graph.SWEEP_HOT_PANELS = args.sweep_hot_panels
+    if args.sweep_thresh:
+        graph.ROW_THRESH = args.sweep_thresh
     if args.sweep_panel_kb:
         graph.SWEEP_PANEL_BYTES = args.sweep_panel_kb << 10
     ops = {}
@@ -65,7 +68,7 @@ def main():
         print("sweep=%d: n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d) built in %.1f s" % (sw, op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len, time.time() - t0), flush=True)
         if s.sweep is not None:
             w = s.sweep
-            print("   sweep schedule: %d rows, %d entries, %d units, %d rounds x %d workgroups, panel %d rows" % (w.n_rows, w.n_entries, w.n_units, w.rounds, w.nwg, w.panel_rows), flush=True)
+            print("   sweep schedule: %d rows, %d entries, %d rounds x %d workgroups, panel %d rows" % (w.n_rows, w.n_entries, w.rounds, w.nwg, w.panel_rows), flush=True)
     del row, col, val
     x = torch.randn(1, op.n, args.C, device=dev)
     y = torch.empty_like(x)

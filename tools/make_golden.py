@@ -140,6 +140,19 @@ def main():
         mod.reset_parameters()
         return mod
 
+    def grads(layer, x, *graph_args):
+        """Gradients of the reference module's OWN autograd for a fixed grad_output (what every torch example trains
+        with, examples/pytorch_based/pytorch_hcp_tgcn.py:167-169).  Draws from torch's generator only, so the numpy
+        stream that shapes the other fixtures is untouched."""
+        xg = x.clone().requires_grad_(True)
+        layer.zero_grad()
+        out = layer(xg, *graph_args)
+        torch.manual_seed(2)
+        go = torch.randn_like(out)
+        out.backward(go)
+        return dict(grad_out=go.numpy(), grad_x=xg.grad.numpy(), grad_weight=layer.weight.grad.numpy(),
+                    grad_bias=(layer.bias.grad.numpy() if layer.bias is not None else np.zeros(0, np.float32)))
+
     # ------------------------------------------------------------ a2: GCNCheb
     cases = [("grid784", 3, 1, 8, 5, 2, True), ("grid784", 3, 4, 8, 5, 3, True), ("grid784", 2, 3, 5, 1, 3, True),
              ("grid784", 2, 3, 5, 2, 3, False), ("dti148", 2, 3, 7, 25, 3, True), ("rmat1024", 2, 8, 16, 10, 3, True),
@@ -165,10 +178,11 @@ def main():
              kind="GCNCheb", K=K, x=x.numpy(), weight=layer.weight.detach().numpy(),
              bias=(layer.bias.detach().numpy() if bias else np.zeros(0, np.float32)), has_bias=int(bias),
              out=out.numpy(), stack=stack.numpy() if stack.numel() < 150000 else np.zeros(0, np.float32),
-             third_party_restated=0, **csr_arrays(L))
+             third_party_restated=0, **grads(layer, x), **csr_arrays(L))
 
     # ----------------------------------------------------------- a3: TGCNCheb
-    for gname, q, f, g, K, bias in (("grid784", 3, 4, 6, 5, True), ("dti148", 4, 2, 3, 4, False), ("pad48", 2, 3, 4, 6, True)):
+    for gname, q, f, g, K, bias in (("grid784", 3, 4, 6, 5, True), ("dti148", 4, 2, 3, 4, False), ("pad48", 2, 3, 4, 6, True),
+                                    ("rmat1024", 2, 16, 16, 5, True)):
         L = graphs[gname]
         n = L.shape[0]
         Ld = torch.tensor(L.toarray(), dtype=torch.float32)
@@ -183,7 +197,8 @@ def main():
         save("TGCNCheb_%s_q%d_f%d_g%d_K%d%s" % (gname, q, f, g, K, "" if bias else "_nobias"), kind="TGCNCheb", K=K,
              x=x.numpy(), weight=layer.weight.detach().numpy(),
              bias=(layer.bias.detach().numpy() if bias else np.zeros(0, np.float32)), has_bias=int(bias),
-             out=out.numpy(), stack=stack.numpy(), third_party_restated=0, **csr_arrays(L))
+             out=out.numpy(), stack=stack.numpy() if stack.numel() < 150000 else np.zeros(0, np.float32), third_party_restated=0,
+             **grads(layer, x), **csr_arrays(L))
 
     # --------------------------------------------------------- a1: TGCNCheb_H
     for gname, q, f, g, K, H, xdim, bias in (("grid784", 3, 1, 8, 5, 28, 3, True), ("dti148", 4, 1, 32, 10, 15, 3, True),
@@ -204,7 +219,7 @@ def main():
              K=K, H=H, x=x.numpy(), weight=layer.weight.detach().numpy(),
              bias=(layer.bias.detach().numpy() if bias else np.zeros(0, np.float32)), has_bias=int(bias),
              out=out.numpy(), stack=stack.numpy() if stack.numel() < 150000 else np.zeros(0, np.float32),
-             third_party_restated=0, **csr_arrays(L))
+             third_party_restated=0, **grads(layer, x), **csr_arrays(L))
 
     # ----------------------------------------------- a4/a5: ChebConv / ChebTimeConv
     def edge_index_of(Acsr, self_loops=0, isolate=None, shuffle=True):
@@ -237,7 +252,8 @@ def main():
         save("ChebConv_%s_q%d_f%d_g%d_K%d_x%dd%s%s" % (gname, q, f, g, K, xdim, "_w" if use_w else "", "" if bias else "_nobias"),
              kind="ChebConv", K=K, n=np.int64(n), x=x.numpy(), edge_index=ei, edge_weight=w, use_weight=int(use_w),
              weight=layer.weight.detach().numpy(), bias=(layer.bias.detach().numpy() if bias else np.zeros(0, np.float32)),
-             has_bias=int(bias), out=out.numpy(), third_party_restated=1)
+             has_bias=int(bias), out=out.numpy(), third_party_restated=1,
+             **grads(layer, x, torch.tensor(ei), torch.tensor(w) if use_w else None))
 
     for gname, Acsr, q, f, g, K, H, xdim, bias, nloops, iso, use_w in (
             ("dti148", A_dti, 3, 1, 32, 25, 15, 3, True, 0, None, False), ("grid784", A_grid, 2, 1, 8, 5, 12, 3, True, 3, None, False),
@@ -252,7 +268,8 @@ def main():
         save("ChebTimeConv_%s_q%d_f%d_g%d_K%d_H%d%s%s" % (gname, q, f, g, K, H, "_w" if use_w else "", "" if bias else "_nobias"),
              kind="ChebTimeConv", K=K, H=H, n=np.int64(n), x=x.numpy(), edge_index=ei, edge_weight=w, use_weight=int(use_w),
              weight=layer.weight.detach().numpy(), bias=(layer.bias.detach().numpy() if bias else np.zeros(0, np.float32)),
-             has_bias=int(bias), out=out.numpy(), third_party_restated=1)
+             has_bias=int(bias), out=out.numpy(), third_party_restated=1,
+             **grads(layer, x, torch.tensor(ei), torch.tensor(w) if use_w else None))
 
     # ------------------------------------------------ a6: spmm / spmm_batch_2 / spmm_batch_3
     ei, w = edge_index_of(A_grid, 3, None)
