@@ -90,6 +90,9 @@ typedef struct tgcn_csr_sched {
   const int16_t* sw_slot;   /* [sw_gptr[last]] slot (row inside its workgroup) of every entry */
   const int32_t* sw_gptr;   /* [sw_rounds*sw_nwg*sw_groups + 1] */
   const int32_t* sw_slot_row;   /* [sw_rounds*sw_nwg*sw_slots] row written from this slot, or -1 */
+  const int32_t* sw_pptr;       /* [streams * sw_nbar] end of each of the first sw_nbar panels inside every stream */
+  int32_t sw_nbar;              /* listed panels per stream (>= 1); in round 0 each ends with a rendezvous of the launch's workgroups */
+  int32_t sw_reserved;
 } tgcn_csr_sched;
 
 /* Batched dense operand: element (b, i, c) lives at ptr[b*batch_stride + i*row_stride + c]. */
@@ -175,6 +178,17 @@ int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sche
 int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t nb, int32_t C,
                       const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Z2, float gamma,
                       const tgcn_dense* Y, const tgcn_dense* P, void* workspace, size_t workspace_bytes);
+
+/* The same hop in fp64 for the numpy twin gcn.graph.chebyshev(L, X, K) with a float64 operand: the reference computes in
+ * L.dtype (gcn/graph.py:247, 256-265).  Plain CSR (int32 rowptr / col, fp64 val), X / Z / Y / P: rows of F contiguous doubles;
+ * Y = alpha * (L X) + beta * Z (Z nullable), P = L X (nullable).  Entries are summed in stored order. */
+int tgcn_csr_hop_f64(void* stream, int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, int64_t F,
+                     const double* X, const double* Z, double alpha, double beta, double* Y, double* P);
+
+/* Change of basis of a (K, CN) weight between the dense-L classes' recursion Xt[k] = 2 L^k x - Xt[k-2] (gcn.py:75-78) and the
+ * monomials L^j x the kernels work in:  out[j, :] = sum_k fold[k, j] W[k, :]  (transpose != 0: sum_k fold[j, k] W[k, :], the
+ * adjoint, for the weight gradient).  fold: K x K device matrix (tgcn_amd/functional.py::power_fold_matrix). */
+int tgcn_fold_weight_f32(void* stream, int32_t K, int64_t CN, const float* fold, const float* W, float* out, int32_t transpose);
 
 /* Stacked-hop dense projection (gcn.py:39,113,194 einsum; :420-431 / :519-527 per-hop matmul):
  *   out[r(m), :] (+)= sum_t A_t[m, 0:Kc] . W[t*Kc:(t+1)*Kc, 0:N] + bias

@@ -158,7 +158,19 @@ def test_graph_chebyshev_golden(path, gpu_device):
     L = O.csr_from_arrays(g["n"], g["rowptr"], g["col"], g["val"]).astype(g["val"].dtype)
     out = chebyshev(L, g["X"], int(g["K"]))
     assert out.dtype == g["out"].dtype and out.shape == g["out"].shape
-    assert rel_err(out, g["out"]) <= TOL
+    # float64 operands keep the reference's fp64 arithmetic (gcn/graph.py:247): only the order of each row's sum may differ
+    assert rel_err(out, g["out"]) <= (1e-13 if out.dtype == np.float64 else TOL)
+
+
+def test_graph_chebyshev_float64_nd_branch(gpu_device):
+    """N-D input with a float64 operand: the reference's reshape-not-permute recurrence (gcn/graph.py:267-283) in fp64"""
+    from tgcn_amd.numpy_api import chebyshev
+    g = load_golden([p for p in golden_files("graph_chebyshev3d")][0])
+    L = O.csr_from_arrays(g["n"], g["rowptr"], g["col"], g["val"]).astype(np.float64)
+    X = g["X"].astype(np.float64)
+    out = chebyshev(L, X, int(g["K"]))
+    ref = O.graph_chebyshev(L, X, int(g["K"]))
+    assert out.dtype == np.float64 and rel_err(out, ref) <= 1e-13
 
 
 def test_pool_golden(gpu_device):

@@ -78,6 +78,10 @@ def test_sweep_builder_replay_cpu(lanes, nwg):
             sl = slice(gptr[wg * G + g], gptr[wg * G + g + 1])
             key = np.minimum(rank[ent[sl, 0]] // 97, graph.SWEEP_HOT_PANELS) * sw.slots + slot[sl]
             assert np.all(np.diff(key) >= 0)
+            if sw.nbar:                                    # where each of the first nbar panels ends inside the stream
+                pan = np.minimum(rank[ent[sl, 0]] // 97, graph.SWEEP_HOT_PANELS)
+                want = gptr[wg * G + g] + np.searchsorted(pan, np.arange(sw.nbar), side="right")
+                assert np.array_equal(sw.pptr.numpy()[wg * G + g], want)
 
 
 def test_sweep_not_built_for_small_operands():

@@ -26,7 +26,8 @@ class SchedStruct(C.Structure):
                 ("blk_row", C.c_void_p), ("seg_row", C.c_void_p), ("seg_e0", C.c_void_p), ("seg_e1", C.c_void_p),
                 ("seg_slot", C.c_void_p), ("long_row", C.c_void_p), ("long_slot", C.c_void_p),
                 ("sw_rounds", C.c_int32), ("sw_nwg", C.c_int32), ("sw_groups", C.c_int32), ("sw_slots", C.c_int32),
-                ("sw_ent", C.c_void_p), ("sw_slot", C.c_void_p), ("sw_gptr", C.c_void_p), ("sw_slot_row", C.c_void_p)]
+                ("sw_ent", C.c_void_p), ("sw_slot", C.c_void_p), ("sw_gptr", C.c_void_p), ("sw_slot_row", C.c_void_p),
+                ("sw_pptr", C.c_void_p), ("sw_nbar", C.c_int32), ("sw_reserved", C.c_int32)]
 
 
 class DenseStruct(C.Structure):
@@ -88,6 +89,8 @@ SIGNATURES = {
                                                    _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "tgcn_relu_pool_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_relu_pool_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_fold_weight_f32": (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32]),
+    "tgcn_csr_hop_f64": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "tgcn_pack_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
     "tgcn_pool_max_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_pool_max_bwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),

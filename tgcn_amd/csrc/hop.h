@@ -331,18 +331,105 @@ struct SweepParams {
   const tgcn_edge* ent;
   const int16_t* slot;
   const int32_t* gptr;
+  const int32_t* pptr;       // [streams * nbar] end of the first nbar popularity panels inside every stream (round 0 only uses them)
   const int32_t* slot_row;
-  int32_t rounds, nwg;
+  int32_t* sync;             // [32] zeroed per launch: sync[0] arrival counter, sync[16] give-up flag
+  int32_t rounds, nwg, nbar;
 };
 
 constexpr int kSweepBlock = 1024, kSweepSlotsPerGroup = 8;
 
-// word offset of channel word w of slot sl: rows of >= 64 words are rotated by 16 words per slot so that the four lane groups
-// of a wave, adding to four different slots, use different LDS banks
+// byte-free word offset of the 4 words [w, w+4) (w a multiple of 4) of slot sl: rows of >= 64 words are rotated by 16 words per
+// slot so that the four lane groups of a wave, adding to four different slots, use different LDS banks
 template <int ROWF>
 __device__ __forceinline__ int sweep_word(int sl, int w) {
   if constexpr (ROWF >= 64) return sl * ROWF + ((w + 16 * (sl & 3)) & (ROWF - 1));
   else return sl * ROWF + w;
+}
+
+// Timing-only rendezvous of all workgroups of the launch (speed, never correctness: no data is handed over, so relaxed
+// atomics and no fences): the k-th call returns when gridDim.x * k workgroups have arrived, or after a bounded spin, after
+// which every later call of every workgroup returns at once.
+__device__ __forceinline__ void sweep_rendezvous(int32_t* sync, int k, int nwg_total) {
+  __syncthreads();
+  if (threadIdx.x == 0 && __hip_atomic_load(sync + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    (void)__hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = nwg_total * k;
+    int spins = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > 20000 || __hip_atomic_load(sync + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // ~ a millisecond: a workgroup is not resident
+        __hip_atomic_store(sync + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// One chunk of LPR entries of a lane group's stream.  FULL: all LPR entries exist (no per-entry predicate).  RUNS: consecutive
+// entries of one row are summed in registers and added to the row's slot when the row changes (hot and cold panels: a row has
+// many entries there); otherwise every product goes straight to its slot (warm panels: a row has one or two entries per panel,
+// so run bookkeeping would cost more than it saves).
+template <int LPR, int U, bool FULL, bool RUNS, int ROWF>
+__device__ __forceinline__ void sweep_chunk(const float* __restrict__ Xc, int64_t ldx, float* __restrict__ lds, int c0, int my_c, float my_v,
+                                            int my_s, int cnt, int& cur, float (&acc)[4]) {
+#pragma unroll
+  for (int j0 = 0; j0 < LPR; j0 += U) {              // fully unrolled: the broadcast lane is an immediate
+    if (FULL || j0 < cnt) {
+      float xv[U][4];
+      float vv[U];
+      int ss[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = group_bcast<LPR>(my_c, j0 + u);
+        vv[u] = __int_as_float(group_bcast<LPR>(__float_as_int(my_v), j0 + u));
+        ss[u] = group_bcast<LPR>(my_s, j0 + u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[u][i] = 0.f;
+        if (FULL || j0 + u < cnt) load_vec<4>(Xc + (int64_t)c * ldx, xv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (FULL || j0 + u < cnt) {
+          if constexpr (RUNS) {
+            if (ss[u] != cur) {                          // same for the lanes of a group: the next row of this chunk
+              float* sl = lds + sweep_word<ROWF>(cur, c0);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) (void)__hip_atomic_fetch_add(sl + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              cur = ss[u];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(vv[u], xv[u][i], acc[i]);
+          } else {
+            float* sl = lds + sweep_word<ROWF>(ss[u], c0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) (void)__hip_atomic_fetch_add(sl + i, vv[u] * xv[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+}
+
+// entries [e0, e1) of one stream; the next chunk's entries are loaded under this chunk's gathers
+template <int LPR, int U, bool RUNS, int ROWF, int NTM>
+__device__ __forceinline__ void sweep_range(const SweepParams& s, const float* __restrict__ Xc, int64_t ldx, float* __restrict__ lds, int c0, int t,
+                                            int e0, int e1, int& cur, float (&acc)[4]) {
+  int nx_c = 0, nx_s = 0;
+  float nx_v = 0.f;
+  if (e0 + t < e1) { load_edge<NTM>(s.ent, e0 + t, nx_c, nx_v); nx_s = s.slot[e0 + t]; }
+  int e = e0;
+  for (; e + LPR <= e1; e += LPR) {
+    const int my_c = nx_c, my_s = nx_s;
+    const float my_v = nx_v;
+    nx_c = 0; nx_s = 0; nx_v = 0.f;
+    if (e + LPR + t < e1) { load_edge<NTM>(s.ent, e + LPR + t, nx_c, nx_v); nx_s = s.slot[e + LPR + t]; }
+    sweep_chunk<LPR, U, true, RUNS, ROWF>(Xc, ldx, lds, c0, my_c, my_v, my_s, LPR, cur, acc);
+  }
+  if (e < e1) sweep_chunk<LPR, U, false, RUNS, ROWF>(Xc, ldx, lds, c0, nx_c, nx_v, nx_s, e1 - e, cur, acc);
 }
 
 template <int LPR, int NTM, int UU>
@@ -357,58 +444,35 @@ __global__ __launch_bounds__(kSweepBlock) void hop_sweep_kernel(const HopParams 
   const int c0 = t * VEC;
   const bool cact = c0 < p.C;
   const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
+  int n_sync = 0;
   for (int round = 0; round < s.rounds; ++round) {
     const int wg = round * s.nwg + (int)blockIdx.x;
     for (int i = tid; i < SLOTS * ROWF / 4; i += kSweepBlock) reinterpret_cast<float4*>(sweep_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    const int e0 = s.gptr[wg * G + g], e1 = s.gptr[wg * G + g + 1];
+    const int e_begin = s.gptr[wg * G + g], e_end = s.gptr[wg * G + g + 1];
     float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
     int cur = 0;
-    auto flush = [&]() {   // no-return LDS float adds: nothing in the loop waits for them
+    auto flush = [&]() {   // no-return LDS float adds on 4 consecutive words: nothing in the loop waits for them
+      float* sl = sweep_acc + sweep_word<ROWF>(cur, c0);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        (void)__hip_atomic_fetch_add(sweep_acc + sweep_word<ROWF>(cur, c0 + i), acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int i = 0; i < VEC; ++i) (void)__hip_atomic_fetch_add(sl + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     };
-    int nx_c = 0, nx_s = 0;
-    float nx_v = 0.f;
-    if (e0 + t < e1) { load_edge<NTM>(s.ent, e0 + t, nx_c, nx_v); nx_s = s.slot[e0 + t]; }
-    for (int e = e0; e < e1; e += LPR) {
-      const int my_c = nx_c, my_s = nx_s;
-      const float my_v = nx_v;
-      nx_c = 0; nx_s = 0;
-      nx_v = 0.f;
-      if (e + LPR + t < e1) { load_edge<NTM>(s.ent, e + LPR + t, nx_c, nx_v); nx_s = s.slot[e + LPR + t]; }   // next chunk, under this chunk's gathers
-      const int cnt = min(LPR, e1 - e);
-#pragma unroll
-      for (int j0 = 0; j0 < LPR; j0 += U) {              // fully unrolled: the broadcast lane is an immediate
-        if (j0 < cnt) {
-          float xv[U][VEC];
-          float vv[U];
-          int ss[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int c = group_bcast<LPR>(my_c, j0 + u);
-            vv[u] = __int_as_float(group_bcast<LPR>(__float_as_int(my_v), j0 + u));
-            ss[u] = group_bcast<LPR>(my_s, j0 + u);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) xv[u][i] = 0.f;
-            if (j0 + u < cnt) load_vec<VEC>(Xc + (int64_t)c * p.x_ld, xv[u]);
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (j0 + u < cnt) {
-              if (ss[u] != cur) {                          // same for the lanes of a group: the next row of this chunk
-                flush();
-                cur = ss[u];
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-              }
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vv[u], xv[u][i], acc[i]);
-            }
-          }
-        }
-      }
+    // Every stream carries the ends of its first npan panels.  Panel 0 (the most referenced rows of X) and the tail behind the
+    // listed panels are walked with run sums, the warm panels in between product by product.  In round 0 -- most of the entries
+    // that can hit in L2 -- each listed panel ends with a rendezvous of the launch's workgroups, so that the workgroups of an
+    // XCD share a panel while it is resident; the other rounds hold too few entries per panel to pay for one.
+    const int npan = s.nbar;
+    const int32_t* pp = s.pptr + (int64_t)(wg * G + g) * npan;
+    const bool meet = round == 0 && gridDim.y == 1;
+    int e0 = e_begin;
+    for (int seg = 0; seg <= npan; ++seg) {
+      const int e1 = seg < npan ? pp[seg] : e_end;
+      if (seg == 0 || seg == npan) sweep_range<LPR, U, true, ROWF, NTM>(s, Xc, p.x_ld, sweep_acc, c0, t, e0, e1, cur, acc);
+      else { flush(); sweep_range<LPR, U, false, ROWF, NTM>(s, Xc, p.x_ld, sweep_acc, c0, t, e0, e1, cur, acc); }
+      e0 = e1;
+      if (meet && seg < npan) sweep_rendezvous(s.sync, ++n_sync, (int)gridDim.x);
     }
     flush();
     __syncthreads();
@@ -432,6 +496,7 @@ __global__ __launch_bounds__(kSweepBlock) void hop_sweep_kernel(const HopParams 
 template <int LPR>
 inline void launch_sweep(hipStream_t st, const HopParams& p, const SweepParams& s, int nb) {
   constexpr int lds = (kSweepBlock / LPR) * kSweepSlotsPerGroup * LPR * 4 * (int)sizeof(float);
+  if (s.nbar > 0) (void)hipMemsetAsync(s.sync, 0, 128, st);      // arrival counter + give-up flag of the rendezvous
   const int v = g_sweep_loads.load();        // developer A/B (tools/hop_bench.py): row loads in flight per lane
   if (v == 4) {
     allow_large_lds((const void*)hop_sweep_kernel<LPR, 0, 4>, lds);

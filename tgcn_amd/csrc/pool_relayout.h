@@ -110,3 +110,32 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const float* __restri
     out[i] = src[idx[r] * ld_src + c];
   }
 }
+
+// fp64 hop for the numpy twin gcn.graph.chebyshev with float64 operands (the reference computes in L.dtype, gcn/graph.py:247,
+// 256-265): S = L X; P = S (optional); Y = alpha S + beta Z.  One thread per output element, entries in stored order
+// (deterministic); these calls are small (M ~ 1e3 rows, N ~ batch columns), so no schedule.
+__global__ __launch_bounds__(kBlock) void hop_f64_kernel(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const double* __restrict__ val, int64_t F, const double* __restrict__ X,
+                                                         const double* __restrict__ Z, double alpha, double beta,
+                                                         double* __restrict__ Y, double* __restrict__ P) {
+  const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (r >= n || c >= F) return;
+  double acc = 0.0;
+  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) acc = fma(val[e], X[(int64_t)col[e] * F + c], acc);
+  if (P) P[r * F + c] = acc;
+  if (Y) Y[r * F + c] = Z ? fma(alpha, acc, beta * Z[r * F + c]) : alpha * acc;
+}
+
+// out[j, :] = sum_k fold[k, j] * W[k, :]  (transpose != 0: fold[j, k]): the K x K change of basis between the reference's
+// recursion and the monomials (tgcn_amd/functional.py::power_fold_matrix) applied to a (K, CN) weight or weight gradient.
+__global__ __launch_bounds__(kBlock) void fold_weight_kernel(const float* __restrict__ fold, const float* __restrict__ W, float* __restrict__ out,
+                                                             int K, int64_t CN, int transpose) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= CN) return;
+  for (int j = 0; j < K; ++j) {
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a = fmaf(transpose ? fold[j * K + k] : fold[k * K + j], W[(int64_t)k * CN + i], a);
+    out[(int64_t)j * CN + i] = a;
+  }
+}

@@ -92,7 +92,8 @@ int tgcn_hop_groups_per_block(int32_t C, int aligned16) { return C > 0 ? kBlock 
 
 size_t tgcn_csr_hop_workspace_bytes(const tgcn_csr_sched* sched, int32_t nb, int32_t C, int aligned16) {
   if (!sched || C <= 0 || nb <= 0) return 0;
-  return (size_t)sched->npartial * (size_t)nb * (size_t)hop_geom(C, aligned16).cpad * sizeof(float);
+  const size_t sync_bytes = sched->sw_rounds > 0 && sched->sw_nbar > 0 ? 256 : 0;
+  return sync_bytes + (size_t)sched->npartial * (size_t)nb * (size_t)hop_geom(C, aligned16).cpad * sizeof(float);
 }
 
 int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
@@ -127,6 +128,12 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
     if (!S->sw_ent || !S->sw_slot || !S->sw_gptr || !S->sw_slot_row) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null sweep arrays");
     if (nb > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: nb=%d > 65535 with a sweep schedule", nb);
     sw.ent = S->sw_ent; sw.slot = S->sw_slot; sw.gptr = S->sw_gptr; sw.slot_row = S->sw_slot_row;
+    sw.nbar = S->sw_nbar > 0 && S->sw_pptr ? S->sw_nbar : 0;
+    sw.pptr = S->sw_pptr;
+    if (sw.nbar > 0) {      // 128 bytes of the caller's workspace (the segment scratch is unused under a sweep schedule)
+      if (!workspace || workspace_bytes < 128) TGCN_FAIL(TGCN_ERR_WORKSPACE, "hop: workspace %zu < 128", workspace_bytes);
+      sw.sync = (int32_t*)workspace;
+    }
     sw.rounds = S->sw_rounds; sw.nwg = S->sw_nwg;
   }
   if (S->npartial > 0) {
@@ -713,6 +720,28 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
       b1 = dst;
     }
   }
+  return TGCN_OK;
+}
+
+int tgcn_fold_weight_f32(void* stream, int32_t K, int64_t CN, const float* fold, const float* W, float* out, int32_t transpose) {
+  if (K < 1 || K > 4096 || CN < 1 || !fold || !W || !out || W == out) TGCN_FAIL(TGCN_ERR_INVALID, "fold_weight: bad argument");
+  hipLaunchKernelGGL(fold_weight_kernel, dim3(grid_1d(CN)), dim3(kBlock), 0, (hipStream_t)stream, fold, W, out, (int)K, CN, (int)transpose);
+  TGCN_CHECK_LAUNCH("tgcn_fold_weight_f32");
+  return TGCN_OK;
+}
+
+int tgcn_csr_hop_f64(void* stream, int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, int64_t F,
+                     const double* X, const double* Z, double alpha, double beta, double* Y, double* P) {
+  if (n <= 0 || F <= 0 || !rowptr || !X || (!Y && !P)) TGCN_FAIL(TGCN_ERR_INVALID, "hop_f64: bad argument");
+  const int64_t gx = (F + 63) / 64, gy = (n + 3) / 4;
+  if (gx > (int64_t)INT32_MAX || gy > 65535 * 1024LL) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop_f64: grid too large");
+  for (int64_t y0 = 0; y0 < gy; y0 += 65535) {       // grid.y limit: slices of 65535 row tiles
+    const int64_t ny = gy - y0 < 65535 ? gy - y0 : 65535;
+    const int64_t r0 = y0 * 4, rows = (n - r0 < ny * 4) ? n - r0 : ny * 4;
+    hipLaunchKernelGGL(hop_f64_kernel, dim3((unsigned)gx, (unsigned)ny), dim3(kBlock), 0, (hipStream_t)stream, rows, rowptr + r0, col, val, F, X,
+                       Z ? Z + r0 * F : nullptr, alpha, beta, Y ? Y + r0 * F : nullptr, P ? P + r0 * F : nullptr);
+  }
+  TGCN_CHECK_LAUNCH("tgcn_csr_hop_f64");
   return TGCN_OK;
 }
 

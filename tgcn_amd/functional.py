@@ -100,7 +100,7 @@ def cheb_time_windows(op, series, weight_khg, bias, bias_kind, mode=MODE_POWER):
     with torch.no_grad():
         W = weight_khg.float()
         if mode == MODE_POWER and K > 2:
-            W = torch.einsum("kj,khn->jhn", power_fold_matrix(K, W.device), W)
+            W = fold_weight(power_fold_matrix(K, W.device), W)
         W = W.reshape(K * H, N).contiguous()
         x3 = series.float().contiguous()
         stack = _monomial_stack(op, x3, K) if mode == MODE_POWER else cheb_stack(op, x3, K, MODE_CHEBYSHEV)   # (K, S, n, T)
@@ -218,6 +218,18 @@ def _power_fold_matrix(K, device=None, dtype=torch.float32):
     return c.to(device=device, dtype=dtype)
 
 
+def fold_weight(fold, W, transpose=False):
+    """W'[j] = sum_k fold[k, j] W[k]  (transpose: sum_k fold[j, k] W[k]) for a (K, C, N) weight, in libtgcn_hip.so: the
+    forward path issues no vendor-library GEMM"""
+    _lib.require_device(fold, W)
+    K = W.shape[0]
+    Wc = W.contiguous()
+    out = torch.empty_like(Wc)
+    _lib.check(_lib.lib().tgcn_fold_weight_f32(_lib.stream_ptr(), K, Wc.numel() // K, _lib.ptr(fold), _lib.ptr(Wc), _lib.ptr(out),
+                                               1 if transpose else 0))
+    return out
+
+
 # ----------------------------------------------------------------------------------------- autograd
 def small_path_tile(op, C_row, mode, pool=False):
     """Channel tile (16 / 8) of the one-launch LDS-resident kernel, or 0 when the shape does not fit it
@@ -292,7 +304,7 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     K, Crow, N = W.shape
     if small_path_tile(op, Crow, mode):
         return cheb_forward_small(op, x3, W, fold, b, bias_kind, mode)
-    Wt = torch.mm(fold.t(), W.reshape(K, Crow * N)).view(K, Crow, N) if fold is not None else W
+    Wt = fold_weight(fold, W) if fold is not None else W
     if use_project_first(x3.shape[0], x3.shape[1], Crow, N):
         return cheb_forward_pf(op, x3, Wt, b, bias_kind, mode)
     return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
@@ -335,7 +347,7 @@ def forward_keeping_basis(op, x3, Wt, bias, bias_kind, mode):
 class ChebLayerFn(torch.autograd.Function):
     """out = sum_k T_k x W_k + bias with T_k given by `mode`; x3 (q,n,C), W (K, C, N) in the REFERENCE basis.
     For MODE_POWER the weight is folded to the monomial basis (W'_j = sum_k c[k,j] W_k): inside the kernel on the
-    small-graph path, by a tiny einsum otherwise; backward applies the transposed fold to the weight gradient."""
+    small-graph path, by tgcn_fold_weight_f32 otherwise; backward applies the transposed fold to the weight gradient."""
 
     @staticmethod
     def forward(ctx, x3, W, bias, op, mode, bias_kind):
@@ -347,7 +359,7 @@ class ChebLayerFn(torch.autograd.Function):
         ctx.basis = None
         general = not small_path_tile(op, Crow, mode) and not use_project_first(x3.shape[0], x3.shape[1], Crow, N)
         if general and K > 1 and ctx.needs_input_grad[1] and K * x3.numel() * 4 <= KEEP_BASIS_BYTES:
-            Wt = torch.mm(fold.t(), W.reshape(K, Crow * N)).view(K, Crow, N) if fold is not None else W
+            Wt = fold_weight(fold, W) if fold is not None else W
             out, rows, nq = forward_keeping_basis(op, x3, Wt, b, bias_kind, mode)
             ctx.basis = (rows, nq)
         else:
@@ -415,7 +427,7 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
     q, n, _ = x3.shape
     Wt = W                                                            # the basis the kernels work in
     if fold is not None and needs[0]:
-        Wt = torch.mm(fold.t(), W.reshape(K, Crow * N)).view(K, Crow, N)
+        Wt = fold_weight(fold, W)
     g = g.contiguous()
     g2d = g.reshape(q * n, N)
     gx = gW = gb = None
@@ -424,7 +436,7 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
         g_rows = relayout_qnc_to_nqc(g).view(q * n, N) if nq else g2d     # same (vertex, sample) row order as the terms
         gW = cheb_wgrad(rows, g_rows)
         if fold is not None:
-            gW = torch.mm(fold, gW.view(K, Crow * N)).view(K, Crow, N)
+            gW = fold_weight(fold, gW, transpose=True)
     elif needs[1]:
         x3c = x3.contiguous()
         if small_basis_tile(op, Crow, mode):                          # small graphs: the whole basis in one launch
@@ -433,7 +445,7 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
             basis = cheb_stack(op, x3c, K, MODE_CHEBYSHEV) if mode == MODE_CHEBYSHEV else _monomial_stack(op, x3c, K)
         gW = cheb_wgrad([basis[k].reshape(q * n, Crow) for k in range(K)], g2d)
         if fold is not None:                                          # back to the reference basis
-            gW = torch.mm(fold, gW.view(K, Crow * N)).view(K, Crow, N)
+            gW = fold_weight(fold, gW, transpose=True)
     if needs[0] and small_path_tile(op.transpose(), N, mode):
         # small graphs: dx = sum_j (L^T)^j g W_j^T is the one-launch forward kernel on (L^T, g, W^T)
         gx = cheb_forward_small(op.transpose(), g, Wt.permute(0, 2, 1).contiguous(), None, None, BIAS_NONE, mode)

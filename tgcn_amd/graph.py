@@ -22,6 +22,7 @@ SWEEP_MIN_ENTRIES = 8_000_000   # entries in rows above ROW_THRESH from which th
 SWEEP_WORKGROUPS = 256          # persistent workgroups per round: one per CU of an MI355X
 SWEEP_PANEL_BYTES = 2 << 20     # rows of X per popularity panel = this / row bytes: half of one XCD's L2
 SWEEP_SLOTS_PER_GROUP = 8
+SWEEP_BARRIER_PANELS = 16      # panels of round 0 that end with a rendezvous of the workgroups (0: free running)
 SWEEP_HOT_PANELS = 64           # popularity panels that are swept one by one; the columns behind them are ONE panel (a unit's cold entries form one run)
 
 
@@ -112,7 +113,8 @@ class Schedule:
                                        self.long_slot.data_ptr(),
                                        sw.rounds if sw else 0, sw.nwg if sw else 0, sw.groups if sw else 0, sw.slots if sw else 0,
                                        sw.ent.data_ptr() if sw else None, sw.slot.data_ptr() if sw else None,
-                                       sw.gptr.data_ptr() if sw else None, sw.slot_row.data_ptr() if sw else None)
+                                       sw.gptr.data_ptr() if sw else None, sw.slot_row.data_ptr() if sw else None,
+                                       sw.pptr.data_ptr() if sw else None, sw.nbar if sw else 0, 0)
 
 
 class SweepSchedule:
@@ -171,6 +173,7 @@ class SweepSchedule:
         key = (e_wg * npan + torch.clamp(cr // P, max=SWEEP_HOT_PANELS)) * slots + e_slot
         o1 = torch.argsort(cr, stable=True)
         o = o1[torch.argsort(key[o1], stable=True)]
+        crp = cr
         del o1, key, cr
         wg_s = e_wg[o]
         per_wg = torch.bincount(e_wg, minlength=R * nwg)
@@ -180,6 +183,17 @@ class SweepSchedule:
         del chunk, wg_s
         o2 = torch.argsort(stream, stable=True)
         per_stream = torch.bincount(stream, minlength=R * nwg * G)
+        # end of each of the first nbar panels inside every stream of round 0
+        nbar = min(SWEEP_BARRIER_PANELS, SWEEP_HOT_PANELS)
+        self.nbar = nbar
+        if nbar:
+            n0 = R * nwg * G                                         # every stream carries its panel ends
+            pan_s = torch.clamp(crp[o] // P, max=SWEEP_HOT_PANELS)
+            sel = pan_s < nbar
+            cnt_sp = torch.bincount(stream[sel] * nbar + pan_s[sel], minlength=n0 * nbar).view(n0, nbar)
+            self.pptr = None                                         # completed below, once gptr is known
+            self._cnt_sp = cnt_sp
+            del pan_s, sel
         o = o[o2]
         del o2, stream
         self.ent = edges[e_idx[o]].contiguous() if nE else torch.zeros((1, 2), dtype=torch.int32, device=dev)
@@ -187,6 +201,11 @@ class SweepSchedule:
         gptr = torch.zeros(R * nwg * G + 1, dtype=torch.int64, device=dev)
         torch.cumsum(per_stream, 0, out=gptr[1:])
         self.gptr = _as_i32(gptr)
+        if self.nbar:
+            self.pptr = _as_i32(gptr[: R * nwg * G, None] + torch.cumsum(self._cnt_sp, 1))
+            del self._cnt_sp
+        else:
+            self.pptr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rounds, self.nwg, self.groups, self.slots = R, nwg, G, slots
         self.n_rows, self.n_entries, self.panel_rows = nL, nE, P
         return self
@@ -264,7 +283,8 @@ class GraphOperand:
         _check_range(row, col, n, n if n_cols is None else n_cols)
         if not (row.numel() == col.numel() == val.numel()):
             raise _lib.TgcnError("graph operand: row / col / val lengths differ")
-        order = torch.argsort(row * (n if n_cols is None else max(n, n_cols)) + col)
+        # stable: duplicates of one (row, col) keep their given order, so two operands built from the same list sum them alike
+        order = torch.argsort(row * (n if n_cols is None else max(n, n_cols)) + col, stable=True)
         counts = torch.bincount(row, minlength=n)
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
         torch.cumsum(counts, 0, out=rowptr[1:])

@@ -21,13 +21,49 @@ def _fingerprint(L):
     return None
 
 
+def _chebyshev_f64(L, X, K, device):
+    """float64 operand: the recursion in fp64 on the device (tgcn_csr_hop_f64), as the reference's L.dtype arithmetic"""
+    import ctypes as C
+    from . import _lib
+    Lc = L.tocsr() if hasattr(L, "tocsr") else __import__("scipy.sparse").sparse.csr_matrix(np.asarray(L))
+    Lc.sort_indices()
+    n = Lc.shape[0]
+    rp = torch.as_tensor(Lc.indptr.astype(np.int32), device=device)
+    ci = torch.as_tensor(Lc.indices.astype(np.int32), device=device)
+    va = torch.as_tensor(Lc.data.astype(np.float64), device=device)
+    lib = _lib.lib()
+
+    def hop(x, z, alpha, beta, y, p):
+        _lib.check(lib.tgcn_csr_hop_f64(_lib.stream_ptr(), n, _lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), x.shape[1], _lib.ptr(x),
+                                        _lib.ptr(z), C.c_double(alpha), C.c_double(beta), _lib.ptr(y), _lib.ptr(p)))
+    sh = X.shape
+    x0 = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float64), device=device)
+    x0 = x0 if X.ndim == 2 else x0.reshape(sh[1], -1)             # N-D: the reference's reshape (not a permute), graph.py:267-283
+    st = torch.empty((K,) + tuple(x0.shape), dtype=torch.float64, device=device)
+    st[0].copy_(x0)
+    if K > 1:
+        hop(st[0], None, 1.0, 0.0, st[1], None)
+    if X.ndim == 2:                                                # Xt[k] = 2 L^k X - Xt[k-2]: running product P
+        bufs = [torch.empty_like(st[0]), torch.empty_like(st[0])]
+        prev = st[1] if K > 1 else None
+        for k in range(2, K):
+            hop(prev, st[k - 2], 2.0, -1.0, st[k], bufs[k % 2])          # P_k = L P_{k-1} (second output), Xt[k] = 2 P_k - Xt[k-2]
+            prev = bufs[k % 2]
+    else:                                                          # true recurrence on the reshaped matrix
+        for k in range(2, K):
+            hop(st[k - 1], st[k - 2], 2.0, -1.0, st[k], None)
+    return st.cpu().numpy().reshape((K,) + sh)
+
+
 def chebyshev(L, X, K, device="cuda"):
     """2-D X (M, N): Xt[0]=X, Xt[1]=L X, Xt[k]=2 L^k X - Xt[k-2]  (graph.py:256-265); returns (K, M, N) in L.dtype.
-    Arithmetic is fp32 on the device (the reference computes in L.dtype; fp64 operands are rounded to fp32).
+    Arithmetic follows L.dtype like the reference: float64 operands run the fp64 hop, everything else the fp32 kernels.
     N-D X: the reference reshapes X to (X.shape[1], -1) WITHOUT permuting (graph.py:267-283), which mixes samples;
     that branch is reproduced literally (true recurrence on the reshaped matrix) because callers depend on it."""
     X = getattr(X, "_value", X)          # autograd boxes are unwrapped like graph.py:249-252
     X = np.asarray(X)
+    if getattr(L, "dtype", None) == np.float64:
+        return _chebyshev_f64(L, X, K, device)
     key = (id(L), getattr(L, "nnz", None), _fingerprint(L), str(device))
     hit = _cache.get(key)
     if hit is None:

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--sweep-loads", default="8", help="comma list: row loads in flight per lane of the sweep kernel (4, 8, 16)")
     ap.add_argument("--sweep-panel-kb", type=int, default=None)
     ap.add_argument("--sweep-hot-panels", type=int, default=None)
+    ap.add_argument("--sweep-barriers", type=int, default=None)
     ap.add_argument("--sweep-thresh", type=int, default=None, help="rows above this many entries go on the sweep schedule (ROW_THRESH)")
     args = ap.parse_args()
     from tools import synth
@@ -51,6 +52,8 @@ def main():
         keep = (deg[row] > thr) if args.only == "long" else (deg[row] <= thr)
         row, col, val = row[keep], col[keep], val[keep]
         print("kept %d entries (%s rows)" % (row.numel(), args.only), flush=True)
+    if args.sweep_barriers is not None:
+        graph.SWEEP_BARRIER_PANELS = args.sweep_barriers
     if args.sweep_hot_panels is not None:
         graph.SWEEP_HOT_PANELS = args.sweep_hot_panels
     if args.sweep_thresh:
