@@ -275,8 +275,7 @@ def main():
         value = (ngroups if vertex_mode else world) * units_per_step * args.steps / dt / 1e9   # vertex mode: ONE graph per group of ranks
 
     # ---- roofline of the dominant kernel (hop_kernel): algorithmic bytes per launch / mean launch duration
-    hop_ms = [ms for kind, ms in prof if kind == 0]          # one per hop: short rows (+ segments when the sweep is off)
-    sweep_ms = [ms for kind, ms in prof if kind == 7]        # one per hop when the long rows are on the sweep schedule
+    hop_ms = [ms for kind, ms in prof if kind == 0]
     proj_ms = [ms for kind, ms in prof if kind == 2]
     fix_ms = [ms for kind, ms in prof if kind == 1]
     C_row = H * spec["f"]
@@ -301,8 +300,7 @@ def main():
                         note="whole layer in one launch; hop tensors never leave LDS, so the HBM roofline on recursion bytes is nominal")
     if hop_ms:
         bytes_per_launch = bytes_recursion / n_hop_launches
-        # a hop is hop_sweep_kernel (rows above 32 entries) followed by hop_kernel (the other rows): its duration is their sum
-        mean_ms = (float(np.sum(hop_ms)) + float(np.sum(sweep_ms))) / len(hop_ms)
+        mean_ms = float(np.mean(hop_ms))
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
         # HBM-side bytes per hop from the rocprofv3 --pmc passes of THIS code (tools/collect_traffic.sh writes the file with
         # the hash of the kernel sources it profiled); a file taken from other sources is stale and reported as null
@@ -319,11 +317,9 @@ def main():
             else:
                 traffic_note = "%s is from other kernel sources (%s, now %s): stale, not reported" % (os.path.relpath(tpath, ROOT), tj.get("source_hash"), _lib.source_hash())
         copy_gbps = measured_copy_gbps(device)
-        roofline = dict(bound="hbm", kernel="hop_sweep_kernel + hop_kernel (one hop)" if sweep_ms else "hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+        roofline = dict(bound="hbm", kernel="hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_note,
                         copy_peak_measured=round(copy_gbps, 1), frac_of_copy_peak=round(achieved / copy_gbps, 4),
-                        sweep_kernel_mean_ms=round(float(np.mean(sweep_ms)), 4) if sweep_ms else None,
-                        row_kernel_mean_ms=round(float(np.mean(hop_ms)), 4),
                         algorithmic_bytes_per_launch=int(bytes_per_launch), launches_per_step=n_hop_launches,
                         path="project-first (hops on C_out-wide rows)" if pf_path else "hops-first",
                         mean_launch_ms=round(mean_ms, 4), hop_ms_per_step=round(float(np.sum(hop_ms)) / args.steps, 3),

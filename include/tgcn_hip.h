@@ -73,26 +73,6 @@ typedef struct tgcn_csr_sched {
   const int32_t* seg_slot;  /* [nseg] scratch slot, or -1: whole row, written directly */
   const int32_t* long_row;  /* [nlong] */
   const int32_t* long_slot; /* [nlong+1] first slot of each long row (slots of a row are consecutive, in column order) */
-  /* ---- ABI v3: sweep schedule of the long rows (sw_rounds == 0: absent, long rows are in the segment arrays above).
-   * Large operands only.  The rows with more than row_thresh entries are dealt, in order of decreasing length, to
-   * sw_nwg persistent 1024-thread workgroups per round, sw_slots rows each; every row owns one accumulator slot of
-   * lanes_per_row*4 floats in its workgroup's LDS.  The entries of a workgroup's rows are sorted by (column popularity
-   * panel, slot, column popularity) and dealt in chunks of lanes_per_row entries to its sw_groups lane groups, round robin;
-   * lane group g of workgroup w walks its chunks as ONE contiguous stream [sw_gptr[w*sw_groups+g], sw_gptr[w*sw_groups+g+1])
-   * of sw_ent / sw_slot.  All lane groups resident on an XCD then sweep the dense operand from its most to its least
-   * referenced rows together, and a row fetched by one of them is served to the others by that XCD's L2.  Several lane
-   * groups add into one slot (LDS float adds), so the summation order of a swept row is not fixed run to run. */
-  int32_t sw_rounds;        /* rounds per launch (0: no sweep) */
-  int32_t sw_nwg;           /* workgroups per round = grid.x of the sweep launch */
-  int32_t sw_groups;        /* lane groups per workgroup = 1024 / lanes_per_row */
-  int32_t sw_slots;         /* accumulator slots (rows) per workgroup = 8 * sw_groups */
-  const tgcn_edge* sw_ent;  /* [sw_gptr[last]] entries of the swept rows in stream order */
-  const int16_t* sw_slot;   /* [sw_gptr[last]] slot (row inside its workgroup) of every entry */
-  const int32_t* sw_gptr;   /* [sw_rounds*sw_nwg*sw_groups + 1] */
-  const int32_t* sw_slot_row;   /* [sw_rounds*sw_nwg*sw_slots] row written from this slot, or -1 */
-  const int32_t* sw_pptr;       /* [streams * sw_nbar] end of each of the first sw_nbar panels inside every stream */
-  int32_t sw_nbar;              /* listed panels per stream (>= 1); in round 0 each ends with a rendezvous of the launch's workgroups */
-  int32_t sw_reserved;
 } tgcn_csr_sched;
 
 /* Batched dense operand: element (b, i, c) lives at ptr[b*batch_stride + i*row_stride + c]. */
@@ -115,7 +95,7 @@ int tgcn_abi_version(void);
  *   from_edge_index  the operand ChebConv / ChebTimeConv build on every forward (gcn.py:398-413 == :495-510) from the
  *                    caller's (2, E) int64 edge list and optional weights: self loops removed, source-degree normalised
  *   tgcn_sched_build the row-block + column-ordered-segment schedule of tgcn_csr_sched for rows of C floats (what
- *                    tgcn_amd/graph.py::Schedule builds; the sweep schedule of very large operands is only built there) */
+ *                    tgcn_amd/graph.py::Schedule builds) */
 typedef struct tgcn_graph tgcn_graph; /* opaque: owns its device arrays */
 typedef struct tgcn_sched tgcn_sched; /* opaque: owns its device arrays */
 int tgcn_graph_create_from_coo(int64_t n, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col, const float* val,
@@ -141,14 +121,12 @@ void tgcn_sched_destroy(tgcn_sched* s);
 #define TGCN_PROF_SMALL 4
 #define TGCN_PROF_WGRAD 5
 #define TGCN_PROF_SMALL_BASIS 6
-#define TGCN_PROF_HOP_SWEEP 7   /* long rows of a hop on the sweep schedule (same hop as the TGCN_PROF_HOP launch that follows) */
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 
 /* Developer switches for A/B runs (tools/hop_bench.py, tools/proj_bench.py; every one is checked against the oracle in
  * tests/test_fuzz_parity.py).  Process-wide, same arithmetic, another kernel; returns TGCN_ERR_INVALID for unknown keys.
  *   "hop_variant"     0 shipped hop kernel; 1.. alternative unroll / row-interleave shapes of hop.h
- *   "sweep_loads"     row loads in flight per lane of hop_sweep_kernel: 8 (default), 4 or 16
  *   "project_variant" 0 auto; 1 exact-fp32 streaming-W; 2 exact-fp32 W-resident with 16-row wave tiles; 3 bf16x3 always;
  *                     4 exact-fp32 auto; 5 vector-ALU narrow kernel wherever it applies
  *   "x3_form"         2 (default) bf16x3 with A fragments from registers for >= 96 output columns; 1 both operands via LDS

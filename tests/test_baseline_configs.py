@@ -106,10 +106,9 @@ def test_cfg4_hcp_style_mesh_T1200(gpu_device):
 @pytest.mark.parametrize("labeling", ["random", "degree"])
 def test_cfg5_reduced_rmat_tgcncheb(labeling, gpu_device):
     """configs[4] at 1/10 scale: R-MAT (0.57, 0.19, 0.19, 0.05), 1 M vertices / 16 M entries, TGCNCheb(L, 64, 64, K=5), 3 time
-    steps, random (worst case) and degree-sorted labels -- the general path the 160 M-entry bench runs: sweep + row kernels for
-    the hops (the sweep schedule is forced on: it switches itself on from 8 M long-row entries), bf16x3 projection, per-vertex bias"""
+    steps, random (worst case) and degree-sorted labels -- the general path the 160 M-entry bench runs: row blocks, column-ordered
+    segments and the fix-up for the hops, bf16x3 projection, per-vertex bias"""
     import tgcn_amd
-    from tgcn_amd import graph
     from tools import synth
     n, nnz = 1_000_000, 16_000_000
     _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling=labeling, device=gpu_device)
@@ -117,7 +116,7 @@ def test_cfg5_reduced_rmat_tgcncheb(labeling, gpu_device):
     del row, col, val
     assert op.nnz == nnz
     sched = op.schedule_for(64, True)
-    assert sched.sweep is not None and sched.sweep.n_entries >= graph.SWEEP_MIN_ENTRIES
+    assert sched.nseg > 0 and sched.nlong > 0 and sched.nhuge > 0          # every long-row path is exercised
     torch.manual_seed(1)
     layer = tgcn_amd.TGCNCheb(op, 64, 64, 5).cuda()
     g = torch.Generator(device="cuda").manual_seed(0)

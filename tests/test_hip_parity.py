@@ -827,3 +827,32 @@ def test_hop_batch_beyond_the_grid_limit(gpu_device):
     Ld.index_put_((torch.as_tensor(row), torch.as_tensor(col)), torch.as_tensor(val).double(), accumulate=True)
     ref = torch.einsum("nm,qmc->qnc", Ld.cuda(), x.double())
     assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("variant", [3, 0])
+def test_bf16x3_projection_mixed_magnitudes(variant, gpu_device):
+    """The three-way bf16 split of the projection (project.h: a = a1 + a2 + a3, six of the nine cross products kept) against
+    fp64 on adversarial ranges: per-row scales 1e-6 ... 1e6, per-term scales spread over 12 decades, terms that cancel, and
+    values near the fp32 denormal range.  Metric per ROW (a large row must not hide a small one): max|a-b| / max|b| <= 1e-5."""
+    from tgcn_amd import functional as F, _lib
+    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", variant))
+    try:
+        rng = np.random.default_rng(7)
+        M, Kc, N, T = 16384, 64, 64, 5
+        row_scale = 10.0 ** rng.uniform(-6, 6, (M, 1))
+        term_scale = 10.0 ** np.array([-6.0, -3.0, 0.0, 3.0, 6.0])
+        terms = [(rng.standard_normal((M, Kc)) * row_scale * ts).astype(np.float32) for ts in term_scale]
+        W = np.stack([(rng.standard_normal((Kc, N)) / ts / np.sqrt(T * Kc)) for ts in term_scale]).astype(np.float32)
+        terms[1][:, :8] = -terms[0][:, :8] * 1e3                    # partial cancellation between terms (W scales differ by 1e3)
+        ref = sum(t.astype(np.float64) @ w.astype(np.float64) for t, w in zip(terms, W))
+        out = F.cheb_project([_dev(t) for t in terms], _dev(W), None, 0, M).cpu().numpy().astype(np.float64)
+        err = np.abs(out - ref).max(axis=1) / np.abs(ref).max(axis=1)
+        assert err.max() <= 1e-5, err.max()
+        # near-denormal inputs: products far below 2^-126 flush to zero in either arithmetic; those just above must survive
+        tiny = [(rng.standard_normal((M, Kc)) * 1e-30).astype(np.float32) for _ in range(T)]
+        Wt = (rng.standard_normal((T, Kc, N)) * 1e-3).astype(np.float32)
+        ref = sum(t.astype(np.float64) @ w.astype(np.float64) for t, w in zip(tiny, Wt))
+        out = F.cheb_project([_dev(t) for t in tiny], _dev(Wt), None, 0, M).cpu().numpy().astype(np.float64)
+        assert np.abs(out - ref).max() / np.abs(ref).max() <= 1e-5
+    finally:
+        _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 0))

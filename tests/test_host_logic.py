@@ -231,3 +231,32 @@ def test_modules_survive_deepcopy_and_pickle():
     assert torch.equal(back.weight, layer.weight) and back._ops._d == {}
     conv = copy.deepcopy(tgcn_amd.ChebConv(2, 3, 4))
     assert conv.weight.shape == (4, 2, 3)
+
+
+def test_operand_cache_is_thread_safe():
+    """nn.DataParallel runs replica forwards in threads that share the module's operand cache (and the fold-matrix cache):
+    concurrent first uses must build each entry once and hand every thread the same object."""
+    import threading
+    from tgcn_amd import functional as F
+    from tgcn_amd.nn import _OperandCache
+    cache = _OperandCache()
+    built = []
+    barrier = threading.Barrier(8)
+    got = [None] * 8
+
+    def build():
+        built.append(1)
+        import time
+        time.sleep(0.01)
+        return object()
+
+    def worker(i):
+        barrier.wait()
+        got[i] = cache.get(("k", i % 2), build)
+        F.power_fold_matrix(7 + i % 2, "cpu")
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(built) == 2
+    assert all(got[i] is got[i % 2] for i in range(8))

@@ -24,10 +24,7 @@ class SchedStruct(C.Structure):
     _fields_ = [("lanes_per_row", C.c_int32), ("row_thresh", C.c_int32), ("nblk", C.c_int32), ("nseg", C.c_int32),
                 ("nlong", C.c_int32), ("nhuge", C.c_int32), ("npartial", C.c_int32), ("reserved", C.c_int32),
                 ("blk_row", C.c_void_p), ("seg_row", C.c_void_p), ("seg_e0", C.c_void_p), ("seg_e1", C.c_void_p),
-                ("seg_slot", C.c_void_p), ("long_row", C.c_void_p), ("long_slot", C.c_void_p),
-                ("sw_rounds", C.c_int32), ("sw_nwg", C.c_int32), ("sw_groups", C.c_int32), ("sw_slots", C.c_int32),
-                ("sw_ent", C.c_void_p), ("sw_slot", C.c_void_p), ("sw_gptr", C.c_void_p), ("sw_slot_row", C.c_void_p),
-                ("sw_pptr", C.c_void_p), ("sw_nbar", C.c_int32), ("sw_reserved", C.c_int32)]
+                ("seg_slot", C.c_void_p), ("long_row", C.c_void_p), ("long_slot", C.c_void_p)]
 
 
 class DenseStruct(C.Structure):

@@ -55,7 +55,6 @@ inline void allow_large_lds(const void* fn, int bytes) {
 }
 
 std::atomic<int> g_hop_variant{0};
-std::atomic<int> g_sweep_loads{8};     // hop_sweep_kernel: row loads in flight per lane (4 / 8 / 16)
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
 std::atomic<int> g_overlap{0};
 std::atomic<int> g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS

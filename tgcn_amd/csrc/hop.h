@@ -314,202 +314,6 @@ __global__ __launch_bounds__(kBlock) void hop_fixup_kernel(const HopParams p) {
   if (valid && c0 < p.C) finish_row<VEC, 0>(p, b, row, c0, acc);
 }
 
-// --------------------------------------------------------------------------------------------------
-// sweep: long rows of large operands, accumulators in LDS, entries walked in order of column popularity
-// --------------------------------------------------------------------------------------------------
-// (include/tgcn_hip.h, tgcn_csr_sched ABI v3.)  One 1024-thread workgroup per CU holds the accumulators of up to
-// 8 * (1024 / lanes_per_row) rows in LDS.  The entries of those rows are sorted by (column popularity panel, row, column
-// popularity) and dealt to the lane groups in chunks of lanes_per_row entries, round robin: every lane group of every
-// resident workgroup is then in the same popularity panel at about the same time, so a row of X fetched by one of them is
-// served to the others by the XCD's L2.  (A first form that gave every lane group its own rows did not hold that lockstep:
-// 32 % L2 hits and 24 GB fetched per launch on the 160 M-entry R-MAT, against 47 % / 19.5 GB for the column-ordered
-// segments; tools/sim models both.)  Consecutive entries of one row are summed in registers and added to the row's slot
-// with no-return LDS float adds when the row changes: several lane groups add to one slot, so the order of those adds -- and
-// with it the last bits of the result -- is not fixed run to run (the reference's scatter_add on a GPU is no different,
-// gcn.py:308,343); the tests bound it by the 1e-5 parity tolerance.
-struct SweepParams {
-  const tgcn_edge* ent;
-  const int16_t* slot;
-  const int32_t* gptr;
-  const int32_t* pptr;       // [streams * nbar] end of the first nbar popularity panels inside every stream (round 0 only uses them)
-  const int32_t* slot_row;
-  int32_t* sync;             // [32] zeroed per launch: sync[0] arrival counter, sync[16] give-up flag
-  int32_t rounds, nwg, nbar;
-};
-
-constexpr int kSweepBlock = 1024, kSweepSlotsPerGroup = 8;
-
-// byte-free word offset of the 4 words [w, w+4) (w a multiple of 4) of slot sl: rows of >= 64 words are rotated by 16 words per
-// slot so that the four lane groups of a wave, adding to four different slots, use different LDS banks
-template <int ROWF>
-__device__ __forceinline__ int sweep_word(int sl, int w) {
-  if constexpr (ROWF >= 64) return sl * ROWF + ((w + 16 * (sl & 3)) & (ROWF - 1));
-  else return sl * ROWF + w;
-}
-
-// Timing-only rendezvous of all workgroups of the launch (speed, never correctness: no data is handed over, so relaxed
-// atomics and no fences): the k-th call returns when gridDim.x * k workgroups have arrived, or after a bounded spin, after
-// which every later call of every workgroup returns at once.
-__device__ __forceinline__ void sweep_rendezvous(int32_t* sync, int k, int nwg_total) {
-  __syncthreads();
-  if (threadIdx.x == 0 && __hip_atomic_load(sync + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-    (void)__hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int target = nwg_total * k;
-    int spins = 0;
-    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > 20000 || __hip_atomic_load(sync + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // ~ a millisecond: a workgroup is not resident
-        __hip_atomic_store(sync + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// One chunk of LPR entries of a lane group's stream.  FULL: all LPR entries exist (no per-entry predicate).  RUNS: consecutive
-// entries of one row are summed in registers and added to the row's slot when the row changes (hot and cold panels: a row has
-// many entries there); otherwise every product goes straight to its slot (warm panels: a row has one or two entries per panel,
-// so run bookkeeping would cost more than it saves).
-template <int LPR, int U, bool FULL, bool RUNS, int ROWF>
-__device__ __forceinline__ void sweep_chunk(const float* __restrict__ Xc, int64_t ldx, float* __restrict__ lds, int c0, int my_c, float my_v,
-                                            int my_s, int cnt, int& cur, float (&acc)[4]) {
-#pragma unroll
-  for (int j0 = 0; j0 < LPR; j0 += U) {              // fully unrolled: the broadcast lane is an immediate
-    if (FULL || j0 < cnt) {
-      float xv[U][4];
-      float vv[U];
-      int ss[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = group_bcast<LPR>(my_c, j0 + u);
-        vv[u] = __int_as_float(group_bcast<LPR>(__float_as_int(my_v), j0 + u));
-        ss[u] = group_bcast<LPR>(my_s, j0 + u);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[u][i] = 0.f;
-        if (FULL || j0 + u < cnt) load_vec<4>(Xc + (int64_t)c * ldx, xv[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (FULL || j0 + u < cnt) {
-          if constexpr (RUNS) {
-            if (ss[u] != cur) {                          // same for the lanes of a group: the next row of this chunk
-              float* sl = lds + sweep_word<ROWF>(cur, c0);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) (void)__hip_atomic_fetch_add(sl + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              cur = ss[u];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[i] = 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fmaf(vv[u], xv[u][i], acc[i]);
-          } else {
-            float* sl = lds + sweep_word<ROWF>(ss[u], c0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) (void)__hip_atomic_fetch_add(sl + i, vv[u] * xv[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        }
-      }
-    }
-  }
-}
-
-// entries [e0, e1) of one stream; the next chunk's entries are loaded under this chunk's gathers
-template <int LPR, int U, bool RUNS, int ROWF, int NTM>
-__device__ __forceinline__ void sweep_range(const SweepParams& s, const float* __restrict__ Xc, int64_t ldx, float* __restrict__ lds, int c0, int t,
-                                            int e0, int e1, int& cur, float (&acc)[4]) {
-  int nx_c = 0, nx_s = 0;
-  float nx_v = 0.f;
-  if (e0 + t < e1) { load_edge<NTM>(s.ent, e0 + t, nx_c, nx_v); nx_s = s.slot[e0 + t]; }
-  int e = e0;
-  for (; e + LPR <= e1; e += LPR) {
-    const int my_c = nx_c, my_s = nx_s;
-    const float my_v = nx_v;
-    nx_c = 0; nx_s = 0; nx_v = 0.f;
-    if (e + LPR + t < e1) { load_edge<NTM>(s.ent, e + LPR + t, nx_c, nx_v); nx_s = s.slot[e + LPR + t]; }
-    sweep_chunk<LPR, U, true, RUNS, ROWF>(Xc, ldx, lds, c0, my_c, my_v, my_s, LPR, cur, acc);
-  }
-  if (e < e1) sweep_chunk<LPR, U, false, RUNS, ROWF>(Xc, ldx, lds, c0, nx_c, nx_v, nx_s, e1 - e, cur, acc);
-}
-
-template <int LPR, int NTM, int UU>
-__global__ __launch_bounds__(kSweepBlock) void hop_sweep_kernel(const HopParams p, const SweepParams s) {
-  constexpr int VEC = 4, G = kSweepBlock / LPR, SPG = kSweepSlotsPerGroup, SLOTS = G * SPG, ROWF = LPR * VEC;
-  constexpr int U = LPR < UU ? LPR : UU;   // row loads in flight per lane: one workgroup per CU, so 8 (128 KB per CU)
-  extern __shared__ float sweep_acc[];                   // SLOTS x ROWF floats = 128 KB
-  const int tid = threadIdx.x;
-  const int t = tid % LPR;
-  const int g = tid / LPR;
-  const int b = blockIdx.y;
-  const int c0 = t * VEC;
-  const bool cact = c0 < p.C;
-  const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
-  int n_sync = 0;
-  for (int round = 0; round < s.rounds; ++round) {
-    const int wg = round * s.nwg + (int)blockIdx.x;
-    for (int i = tid; i < SLOTS * ROWF / 4; i += kSweepBlock) reinterpret_cast<float4*>(sweep_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    const int e_begin = s.gptr[wg * G + g], e_end = s.gptr[wg * G + g + 1];
-    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
-    int cur = 0;
-    auto flush = [&]() {   // no-return LDS float adds on 4 consecutive words: nothing in the loop waits for them
-      float* sl = sweep_acc + sweep_word<ROWF>(cur, c0);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) (void)__hip_atomic_fetch_add(sl + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-    };
-    // Every stream carries the ends of its first npan panels.  Panel 0 (the most referenced rows of X) and the tail behind the
-    // listed panels are walked with run sums, the warm panels in between product by product.  In round 0 -- most of the entries
-    // that can hit in L2 -- each listed panel ends with a rendezvous of the launch's workgroups, so that the workgroups of an
-    // XCD share a panel while it is resident; the other rounds hold too few entries per panel to pay for one.
-    const int npan = s.nbar;
-    const int32_t* pp = s.pptr + (int64_t)(wg * G + g) * npan;
-    const bool meet = round == 0 && gridDim.y == 1;
-    int e0 = e_begin;
-    for (int seg = 0; seg <= npan; ++seg) {
-      const int e1 = seg < npan ? pp[seg] : e_end;
-      if (seg == 0 || seg == npan) sweep_range<LPR, U, true, ROWF, NTM>(s, Xc, p.x_ld, sweep_acc, c0, t, e0, e1, cur, acc);
-      else { flush(); sweep_range<LPR, U, false, ROWF, NTM>(s, Xc, p.x_ld, sweep_acc, c0, t, e0, e1, cur, acc); }
-      e0 = e1;
-      if (meet && seg < npan) sweep_rendezvous(s.sync, ++n_sync, (int)gridDim.x);
-    }
-    flush();
-    __syncthreads();
-    // write the rows: lane group g takes slots g, g + G, ...
-#pragma unroll 1
-    for (int j = 0; j < SPG; ++j) {
-      const int sl = j * G + g;
-      const int row = s.slot_row[(int64_t)wg * SLOTS + sl];
-      if (row < 0) continue;                               // same for the lanes of a group
-      float a[VEC];
-      {
-        const float4 o = *reinterpret_cast<const float4*>(sweep_acc + sweep_word<ROWF>(sl, c0));
-        a[0] = o.x; a[1] = o.y; a[2] = o.z; a[3] = o.w;
-      }
-      if (cact) finish_row<VEC, NTM>(p, b, row, c0, a);
-    }
-    __syncthreads();
-  }
-}
-
-template <int LPR>
-inline void launch_sweep(hipStream_t st, const HopParams& p, const SweepParams& s, int nb) {
-  constexpr int lds = (kSweepBlock / LPR) * kSweepSlotsPerGroup * LPR * 4 * (int)sizeof(float);
-  if (s.nbar > 0) (void)hipMemsetAsync(s.sync, 0, 128, st);      // arrival counter + give-up flag of the rendezvous
-  const int v = g_sweep_loads.load();        // developer A/B (tools/hop_bench.py): row loads in flight per lane
-  if (v == 4) {
-    allow_large_lds((const void*)hop_sweep_kernel<LPR, 0, 4>, lds);
-    hipLaunchKernelGGL((hop_sweep_kernel<LPR, 0, 4>), dim3((unsigned)s.nwg, (unsigned)nb), dim3(kSweepBlock), lds, st, p, s);
-  } else if (v == 16) {
-    allow_large_lds((const void*)hop_sweep_kernel<LPR, 0, 16>, lds);
-    hipLaunchKernelGGL((hop_sweep_kernel<LPR, 0, 16>), dim3((unsigned)s.nwg, (unsigned)nb), dim3(kSweepBlock), lds, st, p, s);
-  } else {
-    allow_large_lds((const void*)hop_sweep_kernel<LPR, 0, 8>, lds);
-    hipLaunchKernelGGL((hop_sweep_kernel<LPR, 0, 8>), dim3((unsigned)s.nwg, (unsigned)nb), dim3(kSweepBlock), lds, st, p, s);
-  }
-}
-
 struct HopGeom {
   int vec, lpr, nchunks, cpad;
 };
@@ -569,20 +373,7 @@ inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3
 template <int L> struct HopRows { static constexpr int value = (L == 64) ? 4 : 1; };
 
 template <int VEC>
-int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid, const SweepParams* sw = nullptr) {
-  if (sw && sw->rounds > 0) {
-    if (VEC != 4) TGCN_FAIL(TGCN_ERR_INVALID, "hop: the sweep schedule needs 16-byte aligned rows");
-    ProfScope ps(TGCN_PROF_HOP_SWEEP, st);
-    switch (lpr) {
-      case 4: launch_sweep<4>(st, p, *sw, (int)grid.y); break;
-      case 8: launch_sweep<8>(st, p, *sw, (int)grid.y); break;
-      case 16: launch_sweep<16>(st, p, *sw, (int)grid.y); break;
-      case 32: launch_sweep<32>(st, p, *sw, (int)grid.y); break;
-      case 64: launch_sweep<64>(st, p, *sw, (int)grid.y); break;
-      default: TGCN_FAIL(TGCN_ERR_INVALID, "hop: sweep schedule with %d lanes per row", lpr);
-    }
-    TGCN_CHECK_LAUNCH("tgcn_csr_hop_f32 (sweep)");
-  }
+int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
 #define TGCN_HOP_CASE(L)                                                                    \
   case L: {                                                                                 \
     { ProfScope ps(TGCN_PROF_HOP, st);                                                      \

@@ -51,7 +51,6 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
 int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
-  if (key && strcmp(key, "sweep_loads") == 0) { g_sweep_loads.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_narrow") == 0) { g_small_narrow.store(value); return TGCN_OK; }
@@ -92,8 +91,7 @@ int tgcn_hop_groups_per_block(int32_t C, int aligned16) { return C > 0 ? kBlock 
 
 size_t tgcn_csr_hop_workspace_bytes(const tgcn_csr_sched* sched, int32_t nb, int32_t C, int aligned16) {
   if (!sched || C <= 0 || nb <= 0) return 0;
-  const size_t sync_bytes = sched->sw_rounds > 0 && sched->sw_nbar > 0 ? 256 : 0;
-  return sync_bytes + (size_t)sched->npartial * (size_t)nb * (size_t)hop_geom(C, aligned16).cpad * sizeof(float);
+  return (size_t)sched->npartial * (size_t)nb * (size_t)hop_geom(C, aligned16).cpad * sizeof(float);
 }
 
 int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
@@ -119,23 +117,6 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
   if (S->nseg < 0 || S->nlong < 0 || S->nhuge < 0 || S->nhuge > S->nlong || S->npartial < 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: bad schedule counts");
   if ((int64_t)nb * g.nchunks > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: nb*chunks=%lld > 65535", (long long)nb * g.nchunks);
   if (S->nseg > 0 && (!S->seg_row || !S->seg_e0 || !S->seg_e1 || !S->seg_slot)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null segment arrays");
-  SweepParams sw;
-  memset(&sw, 0, sizeof(sw));
-  if (S->sw_rounds > 0) {
-    if (g.vec != 4 || g.nchunks != 1 || g.lpr < 4) TGCN_FAIL(TGCN_ERR_INVALID, "hop: sweep schedule needs aligned rows of 16..256 floats (C=%d aligned16=%d)", C, al);
-    if (S->sw_nwg <= 0 || S->sw_nwg > 65535 || S->sw_groups != kSweepBlock / g.lpr || S->sw_slots != kSweepSlotsPerGroup * S->sw_groups)
-      TGCN_FAIL(TGCN_ERR_INVALID, "hop: sweep geometry %d workgroups x %d groups x %d slots does not fit %d lanes per row", S->sw_nwg, S->sw_groups, S->sw_slots, g.lpr);
-    if (!S->sw_ent || !S->sw_slot || !S->sw_gptr || !S->sw_slot_row) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null sweep arrays");
-    if (nb > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: nb=%d > 65535 with a sweep schedule", nb);
-    sw.ent = S->sw_ent; sw.slot = S->sw_slot; sw.gptr = S->sw_gptr; sw.slot_row = S->sw_slot_row;
-    sw.nbar = S->sw_nbar > 0 && S->sw_pptr ? S->sw_nbar : 0;
-    sw.pptr = S->sw_pptr;
-    if (sw.nbar > 0) {      // 128 bytes of the caller's workspace (the segment scratch is unused under a sweep schedule)
-      if (!workspace || workspace_bytes < 128) TGCN_FAIL(TGCN_ERR_WORKSPACE, "hop: workspace %zu < 128", workspace_bytes);
-      sw.sync = (int32_t*)workspace;
-    }
-    sw.rounds = S->sw_rounds; sw.nwg = S->sw_nwg;
-  }
   if (S->npartial > 0) {
     const size_t need = (size_t)S->npartial * nb * g.cpad * sizeof(float);
     if (!workspace || workspace_bytes < need) TGCN_FAIL(TGCN_ERR_WORKSPACE, "hop: workspace %zu < %zu", workspace_bytes, need);
@@ -161,7 +142,7 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
   const int fix_blocks = S->nhuge + (S->nlong - S->nhuge + gpb - 1) / gpb;
   const dim3 fix_grid((unsigned)(fix_blocks > 0 ? fix_blocks : 1), (unsigned)(nb * g.nchunks));
   hipStream_t st = (hipStream_t)stream;
-  return g.vec == 4 ? launch_hop_vec<4>(st, p, g.lpr, grid, fix_grid, &sw) : launch_hop_vec<1>(st, p, g.lpr, grid, fix_grid, &sw);
+  return g.vec == 4 ? launch_hop_vec<4>(st, p, g.lpr, grid, fix_grid) : launch_hop_vec<1>(st, p, g.lpr, grid, fix_grid);
 }
 
 static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,

@@ -4,6 +4,7 @@ Every product, sum and axpy of the forward runs in libtgcn_hip.so (include/tgcn_
 memory, the stream and autograd bookkeeping.  There is no CPU fallback.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -196,13 +197,15 @@ def cheb_stack(op, x3, K, mode):
 
 
 _fold_cache = {}
+_fold_lock = threading.Lock()     # shared by the threads of nn.DataParallel replicas
 
 
 def power_fold_matrix(K, device=None, dtype=torch.float32):
     key = (K, str(device), dtype)
-    c = _fold_cache.get(key)
-    if c is None:
-        c = _fold_cache[key] = _power_fold_matrix(K, device, dtype)
+    with _fold_lock:
+        c = _fold_cache.get(key)
+        if c is None:
+            c = _fold_cache[key] = _power_fold_matrix(K, device, dtype)
     return c
 
 

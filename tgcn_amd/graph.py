@@ -5,6 +5,8 @@ tgcn/nn/gcn.py:141,223 and :408-413,505-510) and cached by the modules.  The pre
 plumbing on torch tensors (sort / cumsum / searchsorted); every flop of the layer runs in libtgcn_hip.so.
 """
 
+import threading
+
 import torch
 
 from . import _lib
@@ -16,14 +18,6 @@ HUGE_SLOTS = 64         # long rows with more segments than this get a whole wor
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
 DENSE_MAX_N = 256       # operands up to this size that store >= 1/4 of their entries also keep a dense copy
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
-# sweep schedule of the long rows (include/tgcn_hip.h, tgcn_csr_sched ABI v3; kernel: csrc/hop.h hop_sweep_kernel)
-SWEEP = True                    # developer switch
-SWEEP_MIN_ENTRIES = 8_000_000   # entries in rows above ROW_THRESH from which the sweep replaces the segments (smaller operands sit in L2 / the Infinity Cache anyway)
-SWEEP_WORKGROUPS = 256          # persistent workgroups per round: one per CU of an MI355X
-SWEEP_PANEL_BYTES = 2 << 20     # rows of X per popularity panel = this / row bytes: half of one XCD's L2
-SWEEP_SLOTS_PER_GROUP = 8
-SWEEP_BARRIER_PANELS = 16      # panels of round 0 that end with a rendezvous of the workgroups (0: free running)
-SWEEP_HOT_PANELS = 64           # popularity panels that are swept one by one; the columns behind them are ONE panel (a unit's cold entries form one run)
 
 
 def _as_i32(t):
@@ -39,16 +33,13 @@ def _check_range(row, col, n, ncol):
 class Schedule:
     """Work schedule for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
 
-    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None, sweep=False, n_cols=None):
+    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None):
         row_thresh = ROW_THRESH if row_thresh is None else row_thresh
         seg_len = max(SEG_LEN if seg_len is None else seg_len, 1)
         dev = rowptr.device
         gpb = 256 // lanes_per_row
         deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
         is_seg = deg > row_thresh
-        self.sweep = None
-        if sweep and edges is not None and lanes_per_row >= 4:
-            self.sweep = SweepSchedule.build(rowptr, edges, n, n if n_cols is None else n_cols, lanes_per_row, row_thresh)
         # ---- short rows: nnz-balanced row blocks
         cost = torch.where(is_seg, torch.zeros_like(deg), deg) + ROW_COST
         cum = torch.cumsum(cost, 0)
@@ -65,8 +56,6 @@ class Schedule:
         self.nblk = nblk
         # ---- longer rows: segments, long rows (several segments) first by decreasing segment count
         seg_rows = is_seg.nonzero().flatten()
-        if self.sweep is not None:          # the long rows are on the sweep schedule: no segments
-            seg_rows = seg_rows[:0]
         z1 = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nseg = self.nlong = self.nhuge = self.npartial = 0
         self.seg_row = self.seg_e0 = self.seg_e1 = self.seg_slot = self.long_row = z1
@@ -106,109 +95,10 @@ class Schedule:
         self.lanes_per_row = lanes_per_row
         self.row_thresh = row_thresh
         self.seg_len = seg_len
-        sw = self.sweep
         self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, 0,
                                        self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
                                        self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
-                                       self.long_slot.data_ptr(),
-                                       sw.rounds if sw else 0, sw.nwg if sw else 0, sw.groups if sw else 0, sw.slots if sw else 0,
-                                       sw.ent.data_ptr() if sw else None, sw.slot.data_ptr() if sw else None,
-                                       sw.gptr.data_ptr() if sw else None, sw.slot_row.data_ptr() if sw else None,
-                                       sw.pptr.data_ptr() if sw else None, sw.nbar if sw else 0, 0)
-
-
-class SweepSchedule:
-    """Sweep schedule of the rows above the row threshold (tgcn_csr_sched ABI v3, include/tgcn_hip.h): which workgroup and
-    accumulator slot every row gets, and the entries of every lane group as one stream -- the workgroup's entries in order
-    of (column popularity panel, slot, column popularity), dealt to its lane groups in chunks of lanes_per_row, round robin.
-    Index plumbing on torch tensors, any device."""
-
-    @staticmethod
-    def build(rowptr, edges, n, n_cols, lanes_per_row, row_thresh, nwg=None, panel_rows=None, force=False):
-        dev = rowptr.device
-        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
-        rows = (deg > row_thresh).nonzero().flatten()
-        if rows.numel() == 0 or lanes_per_row < 4:
-            return None
-        if not force and (not SWEEP or int(deg[rows].sum().item()) < SWEEP_MIN_ENTRIES):
-            return None
-        nwg = SWEEP_WORKGROUPS if nwg is None else nwg
-        G = 1024 // lanes_per_row
-        slots = SWEEP_SLOTS_PER_GROUP * G
-        P = max(1, SWEEP_PANEL_BYTES // (lanes_per_row * 16)) if panel_rows is None else panel_rows
-        self = SweepSchedule()
-        # rows by decreasing length, dealt to the workgroups of a round in snake order: every workgroup gets the same mix
-        order = torch.argsort(deg[rows], descending=True, stable=True)
-        rows = rows[order]
-        dl = deg[rows]
-        nL = rows.numel()
-        ar = torch.arange(nL, device=dev, dtype=torch.int64)
-        per_round = nwg * slots
-        R = -(-nL // per_round)
-        rnd = ar // per_round
-        idx = ar - rnd * per_round
-        pos = idx % (2 * nwg)
-        wg = torch.where(pos < nwg, pos, 2 * nwg - 1 - pos)
-        r_wg = rnd * nwg + wg
-        r_slot = 2 * (idx // (2 * nwg)) + (pos >= nwg).to(torch.int64)
-        self.slot_row = torch.full((R * nwg * slots,), -1, dtype=torch.int32, device=dev)
-        self.slot_row[r_wg * slots + r_slot] = rows.to(torch.int32)
-        # entries of the swept rows
-        nE = int(dl.sum().item())
-        e_rowl = torch.repeat_interleave(ar, dl)
-        e_idx = rowptr[rows].to(torch.int64)[e_rowl] + (torch.arange(nE, device=dev, dtype=torch.int64) - torch.repeat_interleave(torch.cumsum(dl, 0) - dl, dl))
-        col = edges[:, 0][e_idx].to(torch.int64)
-        cnt = torch.bincount(edges[: max(int(rowptr[-1].item()), 1), 0].to(torch.int64), minlength=n_cols)
-        corder = torch.argsort(cnt, descending=True, stable=True)
-        crank = torch.empty(n_cols, dtype=torch.int64, device=dev)
-        crank[corder] = torch.arange(n_cols, device=dev, dtype=torch.int64)
-        del cnt, corder
-        cr = crank[col]
-        del crank, col
-        e_wg = r_wg[e_rowl]
-        e_slot = r_slot[e_rowl]
-        del e_rowl
-        # order inside a workgroup: (panel, slot, popularity); the columns behind the hot panels are one panel
-        npan = SWEEP_HOT_PANELS + 2
-        key = (e_wg * npan + torch.clamp(cr // P, max=SWEEP_HOT_PANELS)) * slots + e_slot
-        o1 = torch.argsort(cr, stable=True)
-        o = o1[torch.argsort(key[o1], stable=True)]
-        crp = cr
-        del o1, key, cr
-        wg_s = e_wg[o]
-        per_wg = torch.bincount(e_wg, minlength=R * nwg)
-        wfirst = torch.cumsum(per_wg, 0) - per_wg
-        chunk = (torch.arange(nE, device=dev, dtype=torch.int64) - wfirst[wg_s]) // lanes_per_row
-        stream = wg_s * G + chunk % G                      # chunks of lanes_per_row entries, round robin over the lane groups
-        del chunk, wg_s
-        o2 = torch.argsort(stream, stable=True)
-        per_stream = torch.bincount(stream, minlength=R * nwg * G)
-        # end of each of the first nbar panels inside every stream of round 0
-        nbar = min(SWEEP_BARRIER_PANELS, SWEEP_HOT_PANELS)
-        self.nbar = nbar
-        if nbar:
-            n0 = R * nwg * G                                         # every stream carries its panel ends
-            pan_s = torch.clamp(crp[o] // P, max=SWEEP_HOT_PANELS)
-            sel = pan_s < nbar
-            cnt_sp = torch.bincount(stream[sel] * nbar + pan_s[sel], minlength=n0 * nbar).view(n0, nbar)
-            self.pptr = None                                         # completed below, once gptr is known
-            self._cnt_sp = cnt_sp
-            del pan_s, sel
-        o = o[o2]
-        del o2, stream
-        self.ent = edges[e_idx[o]].contiguous() if nE else torch.zeros((1, 2), dtype=torch.int32, device=dev)
-        self.slot = e_slot[o].to(torch.int16).contiguous() if nE else torch.zeros(1, dtype=torch.int16, device=dev)
-        gptr = torch.zeros(R * nwg * G + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(per_stream, 0, out=gptr[1:])
-        self.gptr = _as_i32(gptr)
-        if self.nbar:
-            self.pptr = _as_i32(gptr[: R * nwg * G, None] + torch.cumsum(self._cnt_sp, 1))
-            del self._cnt_sp
-        else:
-            self.pptr = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.rounds, self.nwg, self.groups, self.slots = R, nwg, G, slots
-        self.n_rows, self.n_entries, self.panel_rows = nL, nE, P
-        return self
+                                       self.long_slot.data_ptr())
 
 
 class GraphOperand:
@@ -237,9 +127,14 @@ class GraphOperand:
         self.struct = _lib.CsrStruct(self.n, self.nnz, self.rowptr.data_ptr(), self.edges.data_ptr(),
                                      self.dense.data_ptr() if self.dense is not None else None)
         self._sched = {}
+        self._lock = threading.RLock()
         self._transpose = None
         self.perm = None          # reordered(): internal row i holds the caller's vertex perm[i]
         self.inv_perm = None
+
+    def __deepcopy__(self, memo):
+        """An operand is immutable once built (device arrays + ctypes structs that point into them): copies of a module share it."""
+        return self
 
     # ------------------------------------------------------------------ vertex reordering (SURVEY.md 8f-4)
     def reordered(self, kind):
@@ -373,6 +268,10 @@ class GraphOperand:
     def transpose(self):
         """L-hat^T, for the input gradient (L-hat is symmetric for the dense-L classes' usual operand, but
         ChebConv normalises by the source degree only, so the general case is kept)."""
+        with self._lock:
+            return self._transpose_locked()
+
+    def _transpose_locked(self):
         if self._transpose is None:
             row, col, val = self.coo()
             # a rectangular operand (vertex shard: n owned rows x n_cols owned + halo columns) transposes to n_cols x n
@@ -384,20 +283,15 @@ class GraphOperand:
         row, col, val = self.coo()
         return GraphOperand.from_coo(self.n, row, col, val, device, n_cols=self.n_cols)
 
-    def schedule(self, lanes_per_row, sweep=False):
-        """sweep: the caller's rows are 16-byte aligned and fit one lane group (<= 256 floats), so the long rows may go on the
-        sweep schedule (it is only built for large operands, see SweepSchedule.build)."""
-        s = self._sched.get((lanes_per_row, sweep))
-        if s is None:
-            s = self._sched[(lanes_per_row, sweep)] = Schedule(self.rowptr, self.n, lanes_per_row, edges=self.edges, sweep=sweep,
-                                                               n_cols=self.n_cols)
+    def schedule(self, lanes_per_row):
+        with self._lock:                  # replicas of one module may share an operand (nn.DataParallel threads)
+            s = self._sched.get(lanes_per_row)
+            if s is None:
+                s = self._sched[lanes_per_row] = Schedule(self.rowptr, self.n, lanes_per_row, edges=self.edges)
         return s
 
     def schedule_for(self, C_row, aligned16=True):
-        L = _lib.lib()
-        al = 1 if aligned16 else 0
-        sweep = L.tgcn_hop_vec_width(int(C_row), al) == 4 and int(C_row) <= 256
-        return self.schedule(L.tgcn_hop_lanes_per_row(int(C_row), al), sweep)
+        return self.schedule(_lib.lib().tgcn_hop_lanes_per_row(int(C_row), 1 if aligned16 else 0))
 
     def to_scipy(self):
         import scipy.sparse as sp

@@ -6,6 +6,7 @@ The forward of every class is one call into libtgcn_hip.so (K-1 CSR hops + MFMA 
 falls back to torch ops or the CPU.
 """
 import math
+import threading
 
 import torch
 from torch.nn import Parameter
@@ -39,6 +40,7 @@ class _OperandCache:
 
     def __init__(self):
         self._d = {}
+        self._lock = threading.Lock()     # nn.DataParallel runs the replicas' forwards in threads that share this object
 
     # copies and pickles of a module start with an empty cache (entries hold device pointers in ctypes structs)
     def __deepcopy__(self, memo):
@@ -49,14 +51,16 @@ class _OperandCache:
 
     def __setstate__(self, state):
         self._d = {}
+        self._lock = threading.Lock()
 
     def get(self, key, build, sources=()):
-        hit = self._d.get(key)
-        if hit is None:
-            if len(self._d) > 16:
-                self._d.clear()
-            hit = self._d[key] = (build(), tuple(sources))
-        return hit[0]
+        with self._lock:
+            hit = self._d.get(key)
+            if hit is None:
+                if len(self._d) > 16:
+                    self._d.clear()
+                hit = self._d[key] = (build(), tuple(sources))
+            return hit[0]
 
 
 def _np_fingerprint(L):

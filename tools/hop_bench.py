@@ -27,12 +27,6 @@ def main():
     ap.add_argument("--seg-key", default="first")
     ap.add_argument("--only", default="all", choices=["all", "long", "short"], help="keep only the rows above / up to the row threshold (path analysis)")
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
-    ap.add_argument("--sweep", default="1", help="comma list of 0/1: long rows on the sweep schedule (1) or as column-ordered segments (0)")
-    ap.add_argument("--sweep-loads", default="8", help="comma list: row loads in flight per lane of the sweep kernel (4, 8, 16)")
-    ap.add_argument("--sweep-panel-kb", type=int, default=None)
-    ap.add_argument("--sweep-hot-panels", type=int, default=None)
-    ap.add_argument("--sweep-barriers", type=int, default=None)
-    ap.add_argument("--sweep-thresh", type=int, default=None, help="rows above this many entries go on the sweep schedule (ROW_THRESH)")
     args = ap.parse_args()
     from tools import synth
     from tgcn_amd import _lib, graph, functional as F
@@ -52,40 +46,20 @@ def main():
         keep = (deg[row] > thr) if args.only == "long" else (deg[row] <= thr)
         row, col, val = row[keep], col[keep], val[keep]
         print("kept %d entries (%s rows)" % (row.numel(), args.only), flush=True)
-    if args.sweep_barriers is not None:
-        graph.SWEEP_BARRIER_PANELS = args.sweep_barriers
-    if args.sweep_hot_panels is not None:
-        graph.SWEEP_HOT_PANELS = args.sweep_hot_panels
-    if args.sweep_thresh:
-        graph.ROW_THRESH = args.sweep_thresh
-    if args.sweep_panel_kb:
-        graph.SWEEP_PANEL_BYTES = args.sweep_panel_kb << 10
-    ops = {}
-    for sw in [int(v) for v in args.sweep.split(",")]:
-        graph.SWEEP = bool(sw)
-        import time
-        t0 = time.time()
-        op = ops[sw] = graph.GraphOperand.from_coo(args.n, row, col, val, dev)
-        s = op.schedule_for(args.C // args.split)
-        torch.cuda.synchronize()
-        print("sweep=%d: n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d) built in %.1f s" % (sw, op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len, time.time() - t0), flush=True)
-        if s.sweep is not None:
-            w = s.sweep
-            print("   sweep schedule: %d rows, %d entries, %d rounds x %d workgroups, panel %d rows" % (w.n_rows, w.n_entries, w.rounds, w.nwg, w.panel_rows), flush=True)
+    op = graph.GraphOperand.from_coo(args.n, row, col, val, dev)
     del row, col, val
+    s = op.schedule_for(args.C // args.split)
+    print("n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d)" % (op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len), flush=True)
     x = torch.randn(1, op.n, args.C, device=dev)
     y = torch.empty_like(x)
     ref = None
-    variants = [(int(v), sw, sl) for v in args.variants.split(",") for sw in ops for sl in ([int(u) for u in args.sweep_loads.split(",")] if sw else [8])]
+    variants = [int(v) for v in args.variants.split(",")]
     times = {v: [] for v in variants}
     fix = {v: [] for v in variants}
-    sweep_ms = {v: [] for v in variants}
     L = _lib.lib()
     for r in range(args.rounds + 1):
         for v in variants:
-            _lib.check(L.tgcn_set_tuning(b"hop_variant", v[0]))
-            _lib.check(L.tgcn_set_tuning(b"sweep_loads", v[2]))
-            op = ops[v[1]]
+            _lib.check(L.tgcn_set_tuning(b"hop_variant", v))
             _lib.profile_start(16)
             cs = args.C // args.split
             for sp in range(args.split):
@@ -95,18 +69,15 @@ def main():
                 if ref is None:
                     ref = y.clone()
                 else:
-                    err = float((ref - y).abs().max() / ref.abs().max())
-                    assert err <= 1e-5, "variant %s changed the result: %g" % (v, err)
+                    assert torch.equal(ref, y), "variant %d changed the result" % v
                 continue
-            times[v].append(sum(ms for k, ms in prof if k in (0, 7)))
-            sweep_ms[v].append(sum(ms for k, ms in prof if k == 7))
+            times[v].append(sum(ms for k, ms in prof if k == 0))
             fix[v].append(sum(ms for k, ms in prof if k == 1))
     _lib.check(L.tgcn_set_tuning(b"hop_variant", 0))
-    _lib.check(L.tgcn_set_tuning(b"sweep_loads", 8))
     alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph == 'rmat' else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
-        print("hop_variant %d sweep %d loads %d: median %.3f ms  min %.3f ms (sweep kernel %.3f ms)  -> %.0f GB/s algorithmic (cfg5 accounting) = %.3f of 8 TB/s; fixup %.3f ms" % (v[0], v[1], v[2], np.median(t), t.min(), np.median(sweep_ms[v]), alg / np.median(t) / 1e6, alg / np.median(t) / 1e6 / 8000, np.median(fix[v])))
+        print("variant %d: median %.3f ms  min %.3f ms   -> %.0f GB/s algorithmic (cfg5 accounting); fixup %.3f ms" % (v, np.median(t), t.min(), alg / np.median(t) / 1e6, np.median(fix[v])))
 
 
 if __name__ == "__main__":

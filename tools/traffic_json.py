@@ -5,8 +5,7 @@
 
 Per kernel: mean FETCH_SIZE / WRITE_SIZE (KB) / TCC_HIT_sum / TCC_MISS_sum per dispatch.  HBM-side bytes of a kernel
 = (2*FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KB and gfx950 tallies 128-byte read requests at 64 bytes
-(MI355X_MICROARCH.md, HBM).  A hop = hop_sweep_kernel (when the sweep schedule is on) + hop_kernel; bench.py reports the
-sum as roofline.traffic if the recorded source hash still matches the kernel sources."""
+(MI355X_MICROARCH.md, HBM).  bench.py reports hop_kernel's figure as roofline.traffic if the recorded source hash still matches the kernel sources."""
 import collections
 import csv
 import glob
@@ -18,7 +17,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 
 def short(name):
-    for k in ("hop_sweep_kernel", "hop_fixup_kernel", "hop_kernel", "project_x3v2_kernel", "project_x3_kernel", "project_resident_kernel",
+    for k in ("hop_fixup_kernel", "hop_kernel", "project_x3v2_kernel", "project_x3_kernel", "project_resident_kernel",
               "project_kernel", "project_narrow_kernel"):
         if k in name:
             return k
@@ -48,11 +47,10 @@ def main():
             e["tcc_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
         kernels[k] = e
     from tgcn_amd import _lib
-    hop = sum(kernels[k].get("hbm_bytes_per_launch", 0) for k in ("hop_sweep_kernel", "hop_kernel") if k in kernels)
+    hop = kernels.get("hop_kernel", {}).get("hbm_bytes_per_launch", 0)
     json.dump(dict(hbm_bytes_per_hop_launch=hop, kernels=kernels, source_hash=_lib.source_hash(),
                    source="rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, one pass each) of `python3 bench.py --steps 2 --warmup 1 --no-cpu`; "
-                          "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B); "
-                          "one hop = hop_sweep_kernel + hop_kernel"), open(out, "w"), indent=1)
+                          "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B)"), open(out, "w"), indent=1)
     print(open(out).read())
 
 
