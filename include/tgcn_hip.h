@@ -188,6 +188,16 @@ int tgcn_cheb_project_windows_f32(void* stream, int64_t n_vertices, int32_t T, i
                                   const float* const* series, const float* W, const float* bias, int32_t bias_kind,
                                   float* out);
 
+/* Backward of tgcn_cheb_project_windows_f32 for S recordings at once: stack (K, S, n_vertices, T) hop tensors, g the gradient
+ * of the (S*(T-H+1), n_vertices, N) output, W (K*H, N).
+ *   G  (nullable, (K, S, n_vertices, T)):  G[k, s, i, t] = sum_h sum_c g[(s, t-h), i, c] W[k*H + h, c]  -- per-term input
+ *      gradients, which the caller folds with the hop on L^T (Horner / Clenshaw, as for the layer)
+ *   dW (nullable, (K*H, N)):  dW[k*H + h, c] = sum_{s,w,i} stack[k, s, i, w+h] g[(s, w), i, c]; fixed reduction order. */
+size_t tgcn_cheb_windows_wgrad_workspace_bytes(int64_t S, int64_t n_vertices, int32_t T, int32_t H, int32_t N, int32_t K);
+int tgcn_cheb_windows_backward_f32(void* stream, int64_t S, int64_t n_vertices, int32_t T, int32_t H, int32_t N, int32_t K,
+                                   const float* stack, const float* g, const float* W, float* G, float* dW, void* workspace,
+                                   size_t workspace_bytes);
+
 /* Weight gradient of the projection (backward of gcn.py:39,113,194 w.r.t. weight):
  *   dW[t*Kc + c, n] = sum_m A_t[m, c] * G[m, n]
  * A_t as in tgcn_cheb_project_f32 (host arrays of nterms <= 32 pointers / strides), G: M x N with row stride ldg,

@@ -496,6 +496,40 @@ def test_streaming_windows_match_windowed_batch(n, S, T, H, g, K, gpu_device):
     assert rel_err(out_batch.cpu().numpy(), ref) <= TOL
 
 
+@pytest.mark.parametrize("n,S,T,H,g,K", [(148, 2, 40, 15, 32, 10), (300, 3, 33, 7, 8, 3), (500, 1, 20, 20, 5, 4), (64, 2, 16, 5, 70, 1)])
+def test_streaming_windows_backward(n, S, T, H, g, K, gpu_device):
+    """Gradients of forward_series w.r.t. the series, the weight and the bias against the ORACLE's gradients of the layer on the
+    materialised windows (O.layer_backward, pinned by the reference's own autograd), folded back onto the series: the windows
+    the streaming form replaces feed training (load/data_hcp.py:116-154)."""
+    import tgcn_amd
+    rng = np.random.default_rng(n + T)
+    row, col, val = _random_graph(n, 6, rng, hubs=((2, 60),))
+    val = val * 0.4
+    L = O.coo_to_csr(row, col, val, n)
+    layer = tgcn_amd.TGCNCheb_H(torch.tensor(L.toarray(), dtype=torch.float32), 1, g, K, H).cuda()
+    series = rng.standard_normal((S, n, T)).astype(np.float32)
+    nwin = T - H + 1
+    xw = np.stack([series[s, :, w:w + H] for s in range(S) for w in range(nwin)])          # (S*nwin, n, H)
+    W = layer.weight.detach().cpu().numpy()
+    go = rng.standard_normal((S * nwin, n, g)).astype(np.float32)
+    gxw, gW = O.layer_backward(L, xw[..., None], W, go, "power")
+    gs = np.zeros((S, n, T))
+    for s_ in range(S):
+        for w in range(nwin):
+            gs[s_, :, w:w + H] += gxw[s_ * nwin + w, :, :, 0]
+    st = _dev(series).requires_grad_(True)
+    out = layer.forward_series(st)
+    out.backward(_dev(go))
+    assert rel_err(st.grad.cpu().numpy(), gs) <= 2e-5
+    assert rel_err(layer.weight.grad.cpu().numpy(), gW) <= 2e-5
+    assert rel_err(layer.bias.grad.cpu().numpy(), go.astype(np.float64).sum(axis=0, keepdims=True)) <= 2e-5
+    # and the same numbers as training through the materialised windows on the HIP path
+    layer.zero_grad()
+    xt = _dev(xw).requires_grad_(True)
+    layer(xt).backward(_dev(go))
+    assert rel_err(layer.weight.grad.cpu().numpy(), gW) <= 2e-5
+
+
 # ------------------------------------------------------------------------------------------ backward
 @pytest.mark.parametrize("shape", [(60, 3, 5, 4, 2, 6), (300, 2, 4, 7, 4, 64), (90, 5, 3, 1, 1, 40)])
 @pytest.mark.parametrize("small", [True, False])

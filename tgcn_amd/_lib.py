@@ -86,6 +86,9 @@ SIGNATURES = {
                                                    _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "tgcn_relu_pool_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_relu_pool_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tgcn_cheb_windows_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "tgcn_cheb_windows_backward_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P,
+                                                 _P, C.c_size_t]),
     "tgcn_fold_weight_f32": (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32]),
     "tgcn_csr_hop_f64": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "tgcn_pack_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),

@@ -139,3 +139,59 @@ __global__ __launch_bounds__(kBlock) void fold_weight_kernel(const float* __rest
     out[(int64_t)j * CN + i] = a;
   }
 }
+
+// ---- backward of the streaming time-window projection (tgcn_cheb_project_windows_f32):
+//   out[(s, w), i, :] = sum_k sum_h stack[k, s, i, w + h] W[k, h, :]          w in [0, T - H], stack: (K, S, n, T)
+// dgrad: G[k, s, i, t] = sum_h sum_n g[(s, t - h), i, n] W[k, h, n]   (0 <= t - h <= T - H): what the hops on L^T then fold;
+// one thread per (k, s, i, t), g rows read through the cache by the K threads that share them.
+__global__ __launch_bounds__(kBlock) void windows_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ W, float* __restrict__ G,
+                                                               int64_t S, int64_t n, int32_t T, int32_t H, int32_t N, int32_t K) {
+  const int64_t total = (int64_t)K * S * n * T;
+  const int nwin = T - H + 1;
+  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+    const int t = (int)(idx % T);
+    const int64_t i = (idx / T) % n;
+    const int64_t sidx = (idx / T / n) % S;
+    const int k = (int)(idx / T / n / S);
+    const int h0 = t - (nwin - 1) > 0 ? t - (nwin - 1) : 0, h1 = t < H - 1 ? t : H - 1;
+    float acc = 0.f;
+    for (int h = h0; h <= h1; ++h) {
+      const float* gr = g + ((sidx * nwin + (t - h)) * n + i) * N;
+      const float* wr = W + ((int64_t)k * H + h) * N;
+      for (int c = 0; c < N; ++c) acc = fmaf(gr[c], wr[c], acc);
+    }
+    G[idx] = acc;
+  }
+}
+
+// wgrad: dW[k, h, c] = sum_{s, w, i} stack[k, s, i, w + h] g[(s, w), i, c].  Block (k*H + h, column tile of 64, chunk of the
+// (s, w, i) range): 64 column lanes x 4 row lanes, partial sums folded through LDS in lane order, the chunks by a second
+// launch in chunk order (deterministic).
+__global__ __launch_bounds__(kBlock) void windows_wgrad_partial_kernel(const float* __restrict__ stack, const float* __restrict__ g,
+                                                                       float* __restrict__ partial, int64_t S, int64_t n, int32_t T,
+                                                                       int32_t H, int32_t N, int32_t nchunks) {
+  __shared__ float red[4][64];
+  const int kh = blockIdx.x, k = kh / H, h = kh % H;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), ml = threadIdx.x >> 6;
+  const int nwin = T - H + 1;
+  const int64_t M = S * nwin * n, per = (M + nchunks - 1) / nchunks;
+  const int64_t m0 = (int64_t)blockIdx.z * per, m1 = m0 + per < M ? m0 + per : M;
+  float acc = 0.f;
+  if (c < N)
+    for (int64_t m = m0 + ml; m < m1; m += 4) {
+      const int64_t i = m % n, w = (m / n) % nwin, sidx = m / n / nwin;
+      acc = fmaf(stack[(((int64_t)k * S + sidx) * n + i) * T + w + h], g[m * N + c], acc);
+    }
+  red[ml][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (ml == 0 && c < N)
+    partial[((int64_t)blockIdx.z * gridDim.x + kh) * N + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void windows_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int64_t count, int32_t nchunks) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  float acc = 0.f;
+  for (int z = 0; z < nchunks; ++z) acc += partial[(int64_t)z * count + i];
+  dW[i] = acc;
+}

@@ -704,6 +704,37 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
   return TGCN_OK;
 }
 
+static int windows_chunks(int64_t M) { const int64_t c = (M + 16383) / 16384; return (int)(c < 1 ? 1 : (c > 256 ? 256 : c)); }
+
+size_t tgcn_cheb_windows_wgrad_workspace_bytes(int64_t S, int64_t n_vertices, int32_t T, int32_t H, int32_t N, int32_t K) {
+  if (S < 1 || n_vertices < 1 || H < 1 || T < H || N < 1 || K < 1) return 0;
+  return (size_t)windows_chunks(S * (T - H + 1) * n_vertices) * K * H * N * sizeof(float);
+}
+
+int tgcn_cheb_windows_backward_f32(void* stream, int64_t S, int64_t n_vertices, int32_t T, int32_t H, int32_t N, int32_t K,
+                                   const float* stack, const float* g, const float* W, float* G, float* dW, void* workspace,
+                                   size_t workspace_bytes) {
+  if (S < 1 || n_vertices < 1 || H < 1 || T < H || N < 1 || K < 1 || !g) TGCN_FAIL(TGCN_ERR_INVALID, "windows_backward: bad argument");
+  if ((int64_t)K * H > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "windows_backward: K*H > 65535");
+  hipStream_t st = (hipStream_t)stream;
+  if (G) {
+    if (!W) TGCN_FAIL(TGCN_ERR_INVALID, "windows_backward: the input gradient needs W");
+    hipLaunchKernelGGL(windows_dgrad_kernel, dim3(grid_1d((int64_t)K * S * n_vertices * T)), dim3(kBlock), 0, st, g, W, G, S, n_vertices, T, H, N, K);
+  }
+  if (dW) {
+    if (!stack) TGCN_FAIL(TGCN_ERR_INVALID, "windows_backward: the weight gradient needs the hop tensors");
+    const int nchunks = windows_chunks(S * (T - H + 1) * n_vertices);
+    const size_t need = (size_t)nchunks * K * H * N * sizeof(float);
+    if (!workspace || workspace_bytes < need) TGCN_FAIL(TGCN_ERR_WORKSPACE, "windows_backward: workspace %zu < %zu", workspace_bytes, need);
+    hipLaunchKernelGGL(windows_wgrad_partial_kernel, dim3((unsigned)(K * H), (unsigned)((N + 63) / 64), (unsigned)nchunks), dim3(kBlock), 0, st, stack, g,
+                       (float*)workspace, S, n_vertices, T, H, N, nchunks);
+    const int64_t count = (int64_t)K * H * N;
+    hipLaunchKernelGGL(windows_wgrad_reduce_kernel, dim3(grid_1d(count)), dim3(kBlock), 0, st, (const float*)workspace, dW, count, nchunks);
+  }
+  TGCN_CHECK_LAUNCH("tgcn_cheb_windows_backward_f32");
+  return TGCN_OK;
+}
+
 int tgcn_fold_weight_f32(void* stream, int32_t K, int64_t CN, const float* fold, const float* W, float* out, int32_t transpose) {
   if (K < 1 || K > 4096 || CN < 1 || !fold || !W || !out || W == out) TGCN_FAIL(TGCN_ERR_INVALID, "fold_weight: bad argument");
   hipLaunchKernelGGL(fold_weight_kernel, dim3(grid_1d(CN)), dim3(kBlock), 0, (hipStream_t)stream, fold, W, out, (int)K, CN, (int)transpose);

@@ -88,31 +88,90 @@ def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
     return out
 
 
+def _windows_forward(op, x3, W, bias, bias_kind, mode):
+    """x3 (S, n, T) fp32 contiguous, W (K, H, N) in the WORKING basis (folded for MODE_POWER) -> (out, stack (K, S, n, T))"""
+    L = _lib.lib()
+    S, n, T = x3.shape
+    K, H, N = W.shape
+    nwin = T - H + 1
+    stack = _monomial_stack(op, x3, K) if mode == MODE_POWER else cheb_stack(op, x3, K, MODE_CHEBYSHEV)   # (K, S, n, T)
+    out = torch.empty((S * nwin, n, N), dtype=torch.float32, device=x3.device)
+    W2 = W.reshape(K * H, N).contiguous()
+    b = bias.contiguous() if bias is not None else None
+    assert K <= 32, "more than 32 hops: chunk the projection"
+    for s in range(S):
+        ptrs = (C.c_void_p * K)(*[stack[k, s].data_ptr() for k in range(K)])
+        _lib.check(L.tgcn_cheb_project_windows_f32(_lib.stream_ptr(), n, T, H, N, K, ptrs, _lib.ptr(W2), _lib.ptr(b), bias_kind,
+                                                   _lib.ptr(out[s * nwin:])))
+    return out, stack
+
+
+class ChebWindowsFn(torch.autograd.Function):
+    """Streaming time-window layer with its backward: the hops run once on the T columns of every recording in both directions.
+    d series = sum_k T_k(L^T) G_k with G_k the per-term input gradients of the window projection (tgcn_cheb_windows_backward_f32),
+    folded by Horner (mode 0) / Clenshaw (mode 1) hops on L^T exactly as in layer_backward; dW from the same entry point."""
+
+    @staticmethod
+    def forward(ctx, series, weight_khg, bias, op, mode, bias_kind):
+        x3 = series.float().contiguous()
+        W = weight_khg.float().contiguous()
+        K = W.shape[0]
+        fold = power_fold_matrix(K, W.device) if (mode == MODE_POWER and K > 2) else None
+        Wt = fold_weight(fold, W) if fold is not None else W
+        out, stack = _windows_forward(op, x3, Wt, bias, bias_kind, mode)
+        ctx.save_for_backward(x3, Wt)
+        ctx.stack = stack if ctx.needs_input_grad[1] else None       # the basis the weight gradient contracts with g
+        ctx.op, ctx.mode, ctx.fold, ctx.bias_kind = op, mode, fold, bias_kind
+        ctx.bias_shape = None if bias is None else bias.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, Wt = ctx.saved_tensors
+        S, n, T = x3.shape
+        K, H, N = Wt.shape
+        nwin = T - H + 1
+        L = _lib.lib()
+        g = g.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        G = torch.empty((K, S, n, T), dtype=torch.float32, device=g.device) if need_x else None
+        dW = torch.empty((K, H, N), dtype=torch.float32, device=g.device) if need_w else None
+        ws = torch.empty(max(L.tgcn_cheb_windows_wgrad_workspace_bytes(S, n, T, H, N, K), 16), dtype=torch.uint8, device=g.device)
+        _lib.check(L.tgcn_cheb_windows_backward_f32(_lib.stream_ptr(), S, n, T, H, N, K, _lib.ptr(ctx.stack), _lib.ptr(g),
+                                                    _lib.ptr(Wt.reshape(K * H, N)), _lib.ptr(G), _lib.ptr(dW), _lib.ptr(ws), ws.numel()))
+        ctx.stack = None
+        gx = gb = None
+        if need_x:
+            opT = ctx.op.transpose()
+            if K == 1:
+                gx = G[0]
+            elif ctx.mode == MODE_POWER:                              # Horner: b = G_j + L^T b
+                b = G[K - 1]
+                for j in range(K - 2, -1, -1):
+                    b = csr_hop(opT, b, z=G[j], alpha=1.0, beta=1.0)
+                gx = b
+            else:                                                     # Clenshaw on L^T
+                b1, b2 = G[K - 1], None
+                for k in range(K - 2, 0, -1):
+                    t = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0, z2=G[k], gamma=1.0)
+                    b1, b2 = t, b1
+                gx = csr_hop(opT, b1, z=b2, alpha=1.0, beta=-1.0, z2=G[0], gamma=1.0)
+        if need_w and ctx.fold is not None:
+            dW = fold_weight(ctx.fold, dW, transpose=True)
+        if ctx.bias_shape is not None and ctx.needs_input_grad[2]:
+            g4 = g.view(S * nwin, n, N)
+            gb = (g4.sum(dim=(0, 1)) if ctx.bias_kind == BIAS_CHANNEL else g4.sum(dim=0)).reshape(ctx.bias_shape)
+        return gx, dW, gb, None, None, None
+
+
 def cheb_time_windows(op, series, weight_khg, bias, bias_kind, mode=MODE_POWER):
     """Streaming form of TGCNCheb_H / ChebTimeConv on sliding windows (f = 1): series (S, n, T) raw recordings,
     weight (K, H, N) in the reference basis.  Returns (S * (T-H+1), n, N), identical to running the layer on the
     windowed batch x[s*(T-H+1) + w, i, h] = series[s, i, w + h] (load/data_hcp.py:146-152), but the K-1 hops run
-    once on the T columns of each recording.  Inference path (no autograd)."""
+    once on the T columns of each recording -- in the backward too (ChebWindowsFn), so the windows it replaces can be
+    trained through."""
     _lib.require_device(series, weight_khg, bias)
-    L = _lib.lib()
-    S, n, T = series.shape
-    K, H, N = weight_khg.shape
-    nwin = T - H + 1
-    with torch.no_grad():
-        W = weight_khg.float()
-        if mode == MODE_POWER and K > 2:
-            W = fold_weight(power_fold_matrix(K, W.device), W)
-        W = W.reshape(K * H, N).contiguous()
-        x3 = series.float().contiguous()
-        stack = _monomial_stack(op, x3, K) if mode == MODE_POWER else cheb_stack(op, x3, K, MODE_CHEBYSHEV)   # (K, S, n, T)
-        out = torch.empty((S * nwin, n, N), dtype=torch.float32, device=series.device)
-        b = bias.contiguous() if bias is not None else None
-        assert K <= 32, "more than 32 hops: chunk the projection"
-        for s in range(S):
-            ptrs = (C.c_void_p * K)(*[stack[k, s].data_ptr() for k in range(K)])
-            _lib.check(L.tgcn_cheb_project_windows_f32(_lib.stream_ptr(), n, T, H, N, K, ptrs, _lib.ptr(W), _lib.ptr(b), bias_kind,
-                                                       _lib.ptr(out[s * nwin:])))
-    return out
+    return ChebWindowsFn.apply(series, weight_khg, bias, op, mode, bias_kind)
 
 
 def cheb_wgrad(terms, g2d):

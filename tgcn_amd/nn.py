@@ -169,7 +169,7 @@ class TGCNCheb_H(_DenseLBase):
         """Additive API (not in the reference): series (S, n, T) raw recordings -> the layer's output for all
         T-H+1 sliding windows of every recording, (S*(T-H+1), n, g), without materialising the windows
         (load/data_hcp.py:116-154 builds them on the host and the hops then run H times too often).
-        in_channels must be 1.  Inference only."""
+        in_channels must be 1.  Differentiable: the backward runs the hops once per recording too."""
         assert self.in_channels == 1, "forward_series: in_channels must be 1"
         K, H = self.weight.shape[0], self.weight.shape[1]
         W = self.weight.reshape(K, H, self.out_channels)
