@@ -55,6 +55,7 @@ inline void allow_large_lds(const void* fn, int bytes) {
 }
 
 std::atomic<int> g_hop_variant{0};
+std::atomic<int> g_hop_lds_pad{0};      // hop_kernel: bytes of unused dynamic LDS per workgroup (occupancy limiter, developer A/B)
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
 std::atomic<int> g_overlap{0};
 std::atomic<int> g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS

@@ -334,7 +334,10 @@ template <int LPR, int VEC, int U, int R, int NTM = 0>
 inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
   constexpr int GPB = kBlock / LPR;
   grid.x = (unsigned)(p.nblk + (p.nseg + GPB * R - 1) / (GPB * R));
-  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, NTM>), grid, dim3(kBlock), 0, st, p);
+  // "hop_lds_pad": unused dynamic LDS per workgroup = an occupancy limiter (160 KB / pad workgroups per CU) for A/B runs
+  const int pad = g_hop_lds_pad.load();
+  if (pad > 65536) allow_large_lds((const void*)hop_kernel<LPR, VEC, U, R, NTM>, pad);
+  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, NTM>), grid, dim3(kBlock), (size_t)(pad > 0 ? pad : 0), st, p);
 }
 
 // developer variants of the two float4 shapes that matter for the benchmarks (tools/hop_bench.py)

@@ -51,6 +51,7 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
 int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "hop_lds_pad") == 0) { if (value < 0 || value > 160 * 1024) TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: hop_lds_pad %d", value); g_hop_lds_pad.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_narrow") == 0) { g_small_narrow.store(value); return TGCN_OK; }

@@ -156,12 +156,15 @@ class VertexShardedCheb:
             self.send_idx_l = [inv[idx] if idx.numel() else idx for idx in self.send_idx]
         else:
             c2 = c_local
-        is_int = r2 < self.n_int
-        self.op_int = make_operand(self.n_int, self.n_ext, r2[is_int], c2[is_int], v[is_int], self.device) if self.n_int else None
-        nb = self.owned - self.n_int
-        self.op_bnd = make_operand(nb, self.n_ext, r2[~is_int] - self.n_int, c2[~is_int], v[~is_int], self.device) if nb else None
-        # the same rows as one operand (non-overlapped form): identical labels, so both forms sum every row in the same order
-        self.op_all = make_operand(self.owned, self.n_ext, r2, c2, v, self.device) if exchange == "halo" else self.op
+        if exchange == "halo":
+            is_int = r2 < self.n_int
+            self.op_int = make_operand(self.n_int, self.n_ext, r2[is_int], c2[is_int], v[is_int], self.device) if self.n_int else None
+            nb = self.owned - self.n_int
+            self.op_bnd = make_operand(nb, self.n_ext, r2[~is_int] - self.n_int, c2[~is_int], v[~is_int], self.device) if nb else None
+            # the same rows as one operand (non-overlapped form): identical labels, so both forms sum every row in the same order
+            self.op_all = make_operand(self.owned, self.n_ext, r2, c2, v, self.device)
+        else:                       # all-gather: every row waits for the gathered operand, one operand serves both forms
+            self.op_int, self.op_bnd, self.op_all = None, self.op, self.op
 
     # ------------------------------------------------------------------ layer, overlapped
     def _buf(self, name, shape):

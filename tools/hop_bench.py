@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seg-key", default="first")
     ap.add_argument("--only", default="all", choices=["all", "long", "short"], help="keep only the rows above / up to the row threshold (path analysis)")
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
+    ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     args = ap.parse_args()
     from tools import synth
     from tgcn_amd import _lib, graph, functional as F
@@ -53,13 +54,14 @@ def main():
     x = torch.randn(1, op.n, args.C, device=dev)
     y = torch.empty_like(x)
     ref = None
-    variants = [int(v) for v in args.variants.split(",")]
+    variants = [(int(v), int(pd)) for v in args.variants.split(",") for pd in args.lds_pads.split(",")]
     times = {v: [] for v in variants}
     fix = {v: [] for v in variants}
     L = _lib.lib()
     for r in range(args.rounds + 1):
         for v in variants:
-            _lib.check(L.tgcn_set_tuning(b"hop_variant", v))
+            _lib.check(L.tgcn_set_tuning(b"hop_variant", v[0]))
+            _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", v[1] * 1024))
             _lib.profile_start(16)
             cs = args.C // args.split
             for sp in range(args.split):
@@ -69,15 +71,16 @@ def main():
                 if ref is None:
                     ref = y.clone()
                 else:
-                    assert torch.equal(ref, y), "variant %d changed the result" % v
+                    assert torch.equal(ref, y), "variant %s changed the result" % (v,)
                 continue
             times[v].append(sum(ms for k, ms in prof if k == 0))
             fix[v].append(sum(ms for k, ms in prof if k == 1))
     _lib.check(L.tgcn_set_tuning(b"hop_variant", 0))
+    _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", 0))
     alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph == 'rmat' else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
-        print("variant %d: median %.3f ms  min %.3f ms   -> %.0f GB/s algorithmic (cfg5 accounting); fixup %.3f ms" % (v, np.median(t), t.min(), alg / np.median(t) / 1e6, np.median(fix[v])))
+        print("variant %s: median %.3f ms  min %.3f ms   -> %.0f GB/s algorithmic (cfg5 accounting); fixup %.3f ms" % (v, np.median(t), t.min(), alg / np.median(t) / 1e6, np.median(fix[v])))
 
 
 if __name__ == "__main__":
