@@ -140,6 +140,30 @@ def scipy_baseline(op, spec, x, cols=8):
                 sample="%d of the %d columns of 1 of %d samples, K=%d recursion only (no projection), scipy CSR .dot single thread as gcn/graph.py:256-265, %.1f s" % (cols, C_row, spec["q"], spec["K"], dt))
 
 
+def torch_dense_baseline(op, spec, layer, x):
+    """SURVEY.md 8(d) baseline (ii), small graphs only: the reference's own evaluation order on the CPU -- torch einsum with the
+    dense (n, n) operand -- through oracle.cheb_oracle.torch_dense_forward, all host threads torch uses by default."""
+    from oracle import cheb_oracle as O
+    Ld = torch.tensor(op.to_scipy().toarray(), dtype=torch.float32)
+    horizon = spec["cls"] == "TGCNCheb_H"
+    xc = x.float().cpu()
+    if horizon:
+        xc = xc.reshape(xc.shape[0], op.n, spec["H"], spec["f"])
+    elif xc.dim() == 2:
+        xc = xc.unsqueeze(-1)
+    W, b = layer.weight.detach().cpu(), layer.bias.detach().cpu()
+    O.torch_dense_forward(Ld, xc[:1], W, b, horizon)          # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 3.0:
+        out = O.torch_dense_forward(Ld, xc, W, b, horizon)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    units = op.nnz * (spec["K"] - 1) * spec["q"] * spec["H"]
+    return out.numpy(), dict(value=units / dt / 1e9, unit="G edge\u00b7timesteps/s", cores=torch.get_num_threads(), kind="port",
+                             sample="whole batch, dense (n, n) einsum as the reference evaluates it (gcn.py:72-78,147-153,230-236), torch CPU, %d runs of %.1f ms" % (reps, dt * 1e3))
+
+
 def cpu_baseline(op, spec, layer, x, budget_q=1):
     """oracle/cheb_ref.c (reference algorithm: full stack + unfolded weights) on the host cores, on `budget_q`
     of the q samples of the same workload."""
@@ -384,6 +408,11 @@ def main():
         cpu["gpu_vs_cpu_rel_err"] = err
         assert err <= 1e-5, "GPU result differs from the CPU restatement: %g" % err
         cpu["scipy_single_thread"] = scipy_baseline(op, spec, x)
+        if op.n <= 4096 and spec["cls"] in ("GCNCheb", "TGCNCheb_H"):
+            ref2, cpu["torch_dense_einsum"] = torch_dense_baseline(op, spec, layer, x)
+            err2 = float(np.abs(out.cpu().numpy() - ref2).max() / np.abs(ref2).max())
+            cpu["torch_dense_einsum"]["gpu_vs_cpu_rel_err"] = err2
+            assert err2 <= 1e-5, "GPU result differs from the dense-L einsum restatement: %g" % err2
 
     line = None
     if rank == 0:

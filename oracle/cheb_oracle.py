@@ -148,6 +148,23 @@ def cheb_time_conv_forward(x, edge_index, edge_weight, weight, bias):
     return out if bias is None else out + bias
 
 
+def torch_dense_forward(L_dense, x, weight, bias, horizon=False):
+    """The dense-L forward exactly as the reference evaluates it on the CPU -- torch einsum with the (n, n) matrix
+    (tgcn/nn/gcn.py:72-78,147-153,230-236 and :39,113,194) -- for the timed CPU baseline of the small configurations
+    (baseline (ii)).  x (q, n, f) or (q, n, h, f) torch CPU tensors; weight (K, f, g) / (K, H, f, g)."""
+    import torch
+    K = weight.shape[0]
+    Xt = [x]
+    P = x
+    eq = "nm,qmhf->qnhf" if horizon else "nm,qmf->qnf"
+    for k in range(1, K):
+        P = torch.einsum(eq, L_dense, P)
+        Xt.append(P if k == 1 else 2 * P - Xt[k - 2])
+    xc = torch.stack(Xt)
+    out = torch.einsum("kqnhf,khfg->qng" if horizon else "kqnf,kfg->qng", xc, weight)
+    return out if bias is None else out + bias
+
+
 # ----------------------------------------------------------------------------- gradients (what autograd derives)
 def layer_backward(L, x, weight, grad_out, mode):
     """Gradients of out = sum_k T_k(L) x W_k (+ bias) w.r.t. x and weight, in fp64: what torch autograd derives from the

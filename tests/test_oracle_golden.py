@@ -173,3 +173,20 @@ def test_c_port_edge_classes(path):
     W = g["weight"].reshape(g["weight"].shape[0], -1, g["weight"].shape[-1])
     out = _c_forward(g, 1, x.reshape(q, n, -1), W, 1, L=O.coo_to_csr(row, col, lap, n))
     assert rel_err(out, g["out"]) <= TOL
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("GCNCheb_") + golden_files("TGCNChebH_") if "rmat" not in p][:6], ids=lambda p: p.split("/")[-1][:-4])
+def test_torch_dense_baseline_restatement(path):
+    """O.torch_dense_forward (the timed dense-L CPU baseline of the small configurations) against the reference's outputs"""
+    import torch
+    g = load_golden(path)
+    horizon = str(g["kind"]) == "TGCNCheb_H"
+    x = torch.tensor(g["x"])
+    if horizon and x.dim() == 3:
+        x = x.unsqueeze(-1)
+    if not horizon and x.dim() == 2:
+        x = x.unsqueeze(-1)
+    Ld = torch.tensor(_L(g).toarray(), dtype=torch.float32)
+    b = torch.tensor(g["bias"]) if int(g["has_bias"]) else None
+    out = O.torch_dense_forward(Ld, x, torch.tensor(g["weight"]), b, horizon)
+    assert rel_err(out.numpy(), g["out"]) <= TOL
