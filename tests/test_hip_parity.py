@@ -890,3 +890,27 @@ def test_bf16x3_projection_mixed_magnitudes(variant, gpu_device):
         assert np.abs(out - ref).max() / np.abs(ref).max() <= 1e-5
     finally:
         _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 0))
+
+
+def test_from_dense_keeps_only_stored_entries_documented_deviation(gpu_device):
+    """A dense L passed to the dense-L classes is converted to CSR of its NON-ZERO entries (GraphOperand.from_dense).  For
+    finite activations that is the reference's einsum exactly (golden tests); for a non-finite activation the reference's dense
+    product turns every vertex of the sample into NaN (0 * Inf, gcn.py:72,147,230) while the CSR form propagates it to the
+    neighbours only (known deviation).  This pins the sparse semantics."""
+    import tgcn_amd
+    rng = np.random.default_rng(12)
+    n = 2000
+    row, col, val = _random_graph(n, 5, rng)
+    L = O.coo_to_csr(row, col, val, n)
+    Ld = torch.tensor(L.toarray(), dtype=torch.float32)
+    layer = tgcn_amd.GCNCheb(Ld, 4, 3, 3).cuda()
+    x = rng.standard_normal((1, n, 4)).astype(np.float32)
+    x[0, 17, :] = np.inf
+    with torch.no_grad():
+        out = layer(_dev(x)).cpu().numpy()
+    ref = O.gcn_cheb_forward(L.astype(np.float64), x.astype(np.float64), layer.weight.detach().cpu().numpy().astype(np.float64),
+                             layer.bias.detach().cpu().numpy().astype(np.float64))
+    assert np.array_equal(np.isfinite(out), np.isfinite(ref))          # same vertices poisoned as a per-entry (sparse) evaluation
+    assert np.isfinite(out).any() and not np.isfinite(out).all()
+    fin = np.isfinite(ref)
+    assert np.abs(out[fin] - ref[fin]).max() <= 1e-5 * np.abs(ref[fin]).max()
