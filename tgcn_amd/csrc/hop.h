@@ -24,7 +24,7 @@ struct HopParams {
   int64_t x_bs, x_ld, z_bs, z_ld, z2_bs, z2_ld, y_bs, y_ld, p_bs, p_ld;
   float alpha, beta, gamma;
   int32_t nblk, nseg, nlong, nhuge, row_thresh;
-  int32_t C, nb, nchunks, cpad;
+  int32_t C, nb, nchunks, cpad, remap;
 };
 
 template <int VEC>
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
   const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
   int bid = blockIdx.x;
   if (bid < p.nblk) {
-    bid = xcd_remap(bid, p.nblk);
+    if (p.remap) bid = xcd_remap(bid, p.nblk);
     const int r0 = p.blk_row[bid], r1 = p.blk_row[bid + 1];
     for (int rb = r0 + gib; rb < r1; rb += GPB * R) {
       int e0[R], e1[R];

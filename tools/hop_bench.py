@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seg-key", default="first")
     ap.add_argument("--only", default="all", choices=["all", "long", "short"], help="keep only the rows above / up to the row threshold (path analysis)")
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
+    ap.add_argument("--remap", default="1", help="comma list of hop_xcd_remap values, each crossed with the others")
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     args = ap.parse_args()
     from tools import synth
@@ -54,7 +55,7 @@ def main():
     x = torch.randn(1, op.n, args.C, device=dev)
     y = torch.empty_like(x)
     ref = None
-    variants = [(int(v), int(pd)) for v in args.variants.split(",") for pd in args.lds_pads.split(",")]
+    variants = [(int(v), int(pd), int(rm)) for v in args.variants.split(",") for pd in args.lds_pads.split(",") for rm in args.remap.split(",")]
     times = {v: [] for v in variants}
     fix = {v: [] for v in variants}
     L = _lib.lib()
@@ -62,6 +63,7 @@ def main():
         for v in variants:
             _lib.check(L.tgcn_set_tuning(b"hop_variant", v[0]))
             _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", v[1] * 1024))
+            _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", v[2]))
             _lib.profile_start(16)
             cs = args.C // args.split
             for sp in range(args.split):
@@ -77,6 +79,7 @@ def main():
             fix[v].append(sum(ms for k, ms in prof if k == 1))
     _lib.check(L.tgcn_set_tuning(b"hop_variant", 0))
     _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", 0))
+    _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", 1))
     alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph == 'rmat' else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
