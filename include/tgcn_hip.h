@@ -108,6 +108,17 @@ const tgcn_csr* tgcn_graph_csr(const tgcn_graph* g);
 int64_t tgcn_graph_n_cols(const tgcn_graph* g);
 void tgcn_graph_destroy(tgcn_graph* g);
 int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched** out);
+
+/* One level of the reference's Graclus / METIS-style coarsening (gcn/coarsening.py:119-165: a Python loop over vertices and
+ * entries) as host code: HOST arrays in and out -- coarsening is one-off preprocessing of the caller's graph (tgcn_amd/
+ * coarsening.py mirrors coarsen / metis / compute_perm / perm_data / perm_adjacency around it).  Entries sorted by row;
+ * `order` = visiting sequence; an unmatched vertex v joins the unmatched neighbour u with the largest
+ * vv * (1/weight[v] + 1/weight[u]) (first one in entry order on ties), in float / double arithmetic like the reference's
+ * dtype; cluster[v] = cluster index in visiting order. */
+int tgcn_graclus_match_f32(int64_t nnz, const int64_t* rr, const int64_t* cc, const float* vv, int64_t n, const int64_t* order,
+                           const float* weight, int32_t* cluster);
+int tgcn_graclus_match_f64(int64_t nnz, const int64_t* rr, const int64_t* cc, const double* vv, int64_t n, const int64_t* order,
+                           const double* weight, int32_t* cluster);
 const tgcn_csr_sched* tgcn_sched_get(const tgcn_sched* s);
 void tgcn_sched_destroy(tgcn_sched* s);
 

@@ -42,6 +42,8 @@ SIGNATURES = {
     "tgcn_graph_csr": (C.POINTER(CsrStruct), [_P]),
     "tgcn_graph_n_cols": (C.c_int64, [_P]),
     "tgcn_graph_destroy": (None, [_P]),
+    "tgcn_graclus_match_f32": (C.c_int, [C.c_int64, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "tgcn_graclus_match_f64": (C.c_int, [C.c_int64, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "tgcn_sched_build": (C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(_P)]),
     "tgcn_sched_get": (C.POINTER(SchedStruct), [_P]),
     "tgcn_sched_destroy": (None, [_P]),

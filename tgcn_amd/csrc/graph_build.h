@@ -217,3 +217,62 @@ void tgcn_sched_destroy(tgcn_sched* s) { delete s; }
 }  // extern "C"
 
 namespace {
+
+// ---- Graclus / METIS-style greedy matching of one coarsening level (gcn/coarsening.py:119-165 is a Python loop over vertices and
+// their entries).  HOST arrays in, host array out: coarsening is one-off preprocessing of the caller's graph, long before the
+// forward path.  Entries (rr, cc, vv) sorted by row (any order inside a row: the FIRST best neighbour in that order wins, as in
+// the reference); `order` = the sequence in which vertices are visited; `weight` = the vertex weights (degrees).  An unmatched
+// vertex v pairs with its unmatched neighbour u maximising vv * (1/weight[v] + 1/weight[u]), in the arithmetic of T.
+// Row extents are derived the way the reference derives them (coarsening.py:132-141), bit for bit, because every coarser graph
+// depends on the result: rows are numbered in order of appearance (equal to the vertex id when no vertex is isolated) and, with
+// a_k entries in the k-th appearing row, the loop reads a_0 + 1 entries for the first row (one entry of the second row too),
+// a_k for the rows in between and a_k - 1 for the last row.
+template <typename T>
+int graclus_match(int64_t nnz, const int64_t* rr, const int64_t* cc, const T* vv, int64_t n, const int64_t* order, const T* weight,
+                  int32_t* cluster) {
+  if (n <= 0 || nnz <= 0 || !rr || !cc || !vv || !order || !weight || !cluster) TGCN_FAIL(TGCN_ERR_INVALID, "graclus_match: bad argument");
+  if (n != rr[nnz - 1] + 1) TGCN_FAIL(TGCN_ERR_INVALID, "graclus_match: n must be the last row + 1 (coarsening.py:121)");
+  std::vector<int64_t> first((size_t)n + 1, 0), extent((size_t)n + 1, 0);
+  {
+    int64_t seen = 0, current = rr[0];
+    for (int64_t e = 0; e < nnz; ++e) {
+      if (rr[e] < 0 || rr[e] >= n || cc[e] < 0 || cc[e] >= n || (e > 0 && rr[e] < rr[e - 1])) TGCN_FAIL(TGCN_ERR_INVALID, "graclus_match: entries must be sorted by row, inside [0, n)");
+      extent[seen] += 1;
+      if (rr[e] > current) { current = rr[e]; first[seen + 1] = e; ++seen; }
+    }
+  }
+  std::vector<char> taken((size_t)n, 0);
+  int32_t next = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t v = order[i];
+    if (v < 0 || v >= n) TGCN_FAIL(TGCN_ERR_INVALID, "graclus_match: visiting order outside [0, n)");
+    if (taken[v]) continue;
+    taken[v] = 1;
+    int64_t best = -1;
+    T best_w = (T)0;
+    for (int64_t e = first[v]; e < first[v] + extent[v] && e < nnz; ++e) {
+      const int64_t u = cc[e];
+      const T w = taken[u] ? (T)0 : vv[e] * ((T)1 / weight[v] + (T)1 / weight[u]);
+      if (w > best_w) { best_w = w; best = u; }
+    }
+    cluster[v] = next;
+    if (best >= 0) { cluster[best] = next; taken[best] = 1; }
+    ++next;
+  }
+  return TGCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+int tgcn_graclus_match_f32(int64_t nnz, const int64_t* rr, const int64_t* cc, const float* vv, int64_t n, const int64_t* order,
+                           const float* weight, int32_t* cluster) {
+  return graclus_match<float>(nnz, rr, cc, vv, n, order, weight, cluster);
+}
+int tgcn_graclus_match_f64(int64_t nnz, const int64_t* rr, const int64_t* cc, const double* vv, int64_t n, const int64_t* order,
+                           const double* weight, int32_t* cluster) {
+  return graclus_match<double>(nnz, rr, cc, vv, n, order, weight, cluster);
+}
+}  // extern "C"
+
+namespace {

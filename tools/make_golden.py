@@ -7,6 +7,7 @@ Usage (from anywhere, reference mounted read-only at /root/reference):
 
 What is executed from the reference (nothing is copied; only inputs/outputs are stored):
   * gcn.graph            grid / distance_sklearn_metrics / adjacency / laplacian / rescale_L / chebyshev
+  * gcn.coarsening       coarsen / metis / compute_perm / perm_data / perm_adjacency
   * tgcn.nn.gcn_matmul   GCNCheb, TGCNCheb, TGCNCheb_H              (imports with plain torch)
   * tgcn.nn.gcn          GCNCheb, TGCNCheb, TGCNCheb_H, ChebConv, ChebTimeConv, spmm, spmm_batch_2,
                          spmm_batch_3, gcn_pool, gcn_pool_4, uniform
@@ -314,6 +315,36 @@ def main():
         save("operand_%s_lmax%s" % (gname, str(lm).replace(".", "p")), kind="operand", lmax=np.float64(lm), n=np.int64(Acsr.shape[0]),
              a_row=coo.row.astype(np.int64), a_col=coo.col.astype(np.int64), a_val=coo.data.astype(np.float32),
              third_party_restated=0, **{("L_" + k): v for k, v in csr_arrays(Lh).items() if k != "n"})
+
+
+    # ------------------------------------------------ graph coarsening (gcn/coarsening.py), the step in front of the pooling layers
+    import contextlib
+    import io
+    import gcn.coarsening as rco
+    # (the 1024-vertex R-MAT has isolated vertices at the end of its numbering: the reference's matching loop indexes past its
+    # arrays there, coarsening.py:121,142, so it is not a fixture)
+    for gname, Acsr, levels in (("grid784", A_grid, 4), ("dti148", A_dti, 2), ("grid36", A6.tocsr(), 3)):
+        Acsr = Acsr.astype(np.float32).tocsr()
+        np.random.seed(7)                                   # coarsen() draws its first visiting order from numpy's global generator
+        with contextlib.redirect_stdout(io.StringIO()):
+            graphs, perm = rco.coarsen(Acsr, levels=levels, self_connections=False)
+        rid = np.random.RandomState(3).permutation(Acsr.shape[0])
+        g2, parents = rco.metis(Acsr, levels, rid=rid)
+        perms = rco.compute_perm(parents)
+        xs = np.random.RandomState(4).standard_normal((3, Acsr.shape[0]))
+        kw = dict(kind="coarsening", levels=levels, seed=7, a_rowptr=Acsr.indptr.astype(np.int64), a_col=Acsr.indices.astype(np.int32),
+                  a_val=Acsr.data.astype(np.float32), n=np.int64(Acsr.shape[0]), perm=np.asarray(perm, np.int64), rid=rid.astype(np.int64),
+                  x=xs, x_perm=rco.perm_data(xs, perm), third_party_restated=0)
+        for i, G in enumerate(graphs):
+            G = G.tocsr()
+            G.sort_indices()
+            kw.update({"g%d_rowptr" % i: G.indptr.astype(np.int64), "g%d_col" % i: G.indices.astype(np.int32), "g%d_val" % i: G.data.astype(np.float32),
+                       "g%d_n" % i: np.int64(G.shape[0])})
+        for i, p_ in enumerate(parents):
+            kw["parents%d" % i] = np.asarray(p_, np.int32)
+        for i, p_ in enumerate(perms):
+            kw["perms%d" % i] = np.asarray(p_, np.int64)
+        save("coarsen_%s_levels%d" % (gname, levels), **kw)
 
 
 if __name__ == "__main__":
