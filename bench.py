@@ -268,7 +268,7 @@ def main():
     ap.add_argument("--project-variant", type=int, default=None, help="developer: tgcn_set_tuning(project_variant, v)")
     ap.add_argument("--no-small-path", action="store_true", help="developer: disable the one-launch small-graph kernel")
     ap.add_argument("--no-extras", action="store_true", help="N > 1, time sharding: skip the vertex-sharded / hybrid runs reported in `other_shardings`")
-    ap.add_argument("--extras-budget", type=float, default=240.0, help="seconds after which the extra runs are abandoned and the headline line is printed without them")
+    ap.add_argument("--extras-budget", type=float, default=150.0, help="seconds after which the extra runs are abandoned and the headline line is printed without them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
