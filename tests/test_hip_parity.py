@@ -914,3 +914,22 @@ def test_from_dense_keeps_only_stored_entries_documented_deviation(gpu_device):
     assert np.isfinite(out).any() and not np.isfinite(out).all()
     fin = np.isfinite(ref)
     assert np.abs(out[fin] - ref[fin]).max() <= 1e-5 * np.abs(ref[fin]).max()
+
+
+@pytest.mark.parametrize("key,value", [("hop_xcd_remap", 0), ("hop_lds_pad", 40 * 1024), ("hop_lds_pad", 80 * 1024)])
+def test_hop_scheduling_switches_keep_the_result(key, value, gpu_device):
+    """hop_xcd_remap / hop_lds_pad change where and how many workgroups run, never what they compute: bitwise the same hop"""
+    from tgcn_amd import functional as F, _lib
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(21)
+    n, C = 9000, 64
+    row, col, val = _random_graph(n, 9, rng, hubs=((5, 700), (n - 1, 3000)), isolated=(0, 7))
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    x = _dev(rng.standard_normal((2, n, C)).astype(np.float32))
+    base = F.csr_hop(op, x)
+    assert rel_err(base.cpu().numpy(), O._apply(O.coo_to_csr(row, col, val, n), x.cpu().numpy())) <= TOL
+    _lib.check(_lib.lib().tgcn_set_tuning(key.encode(), value))
+    try:
+        assert torch.equal(F.csr_hop(op, x), base)
+    finally:
+        _lib.check(_lib.lib().tgcn_set_tuning(key.encode(), {"hop_xcd_remap": 1, "hop_lds_pad": 0}[key]))
