@@ -36,7 +36,7 @@ namespace {
 template <typename T>
 int fetch(std::vector<T>& dst, const T* dev, size_t count) {
   dst.resize(count);
-  if (count && hipMemcpy(dst.data(), dev, count * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (count && hipMemcpy(dst.data(), dev, count * sizeof(T), hipMemcpyDefault) != hipSuccess) return -1;   // device (the convention) or host memory
   return 0;
 }
 
