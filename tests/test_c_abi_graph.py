@@ -85,11 +85,12 @@ def test_hop_through_bare_ctypes(lib, C_row):
     lib.tgcn_graph_destroy(g)
 
 
-def test_library_schedule_equals_the_python_builder(lib):
-    """tgcn_sched_build against tgcn_amd/graph.py::Schedule, array by array (the Python builder is what the modules use)"""
+@pytest.mark.parametrize("n", [4000, 200000])
+def test_library_schedule_equals_the_python_builder(lib, n):
+    """tgcn_sched_build against tgcn_amd/graph.py::Schedule, array by array (the Python builder is what the modules use);
+    n = 200000 is large enough for the block-size cap of narrow rows to apply"""
     from tgcn_amd.graph import GraphOperand
     rng = np.random.default_rng(2)
-    n = 4000
     deg = rng.integers(0, 25, n)
     deg[rng.integers(0, n, 30)] = rng.integers(33, 3000, 30)
     row = np.repeat(np.arange(n), deg)

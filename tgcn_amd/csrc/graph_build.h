@@ -148,7 +148,8 @@ int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched**
     total += (d > row_thresh ? 0 : d) + row_cost;
     cum[i] = total;
   }
-  const int64_t target = std::max<int64_t>(gpb * 16, std::min<int64_t>(gpb * 256, (total + max_blocks_hint - 1) / max_blocks_hint));
+  const int64_t cap = lanes <= 16 ? 64 : 256;        // narrow rows: small blocks keep an XCD's gather window inside its L2 (tgcn_amd/graph.py)
+  const int64_t target = std::max<int64_t>(gpb * 16, std::min<int64_t>(gpb * cap, (total + max_blocks_hint - 1) / max_blocks_hint));
   const int64_t nblk = std::max<int64_t>(1, (total + target - 1) / target);
   std::vector<int32_t> blk_row;
   blk_row.push_back(0);

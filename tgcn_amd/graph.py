@@ -18,6 +18,7 @@ HUGE_SLOTS = 64         # long rows with more segments than this get a whole wor
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
 DENSE_MAX_N = 256       # operands up to this size that store >= 1/4 of their entries also keep a dense copy
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
+BLOCK_ROWS_MAX = None   # cost of a row block at most this many entry-equivalents per lane group (None: 64 for rows up to 64 floats, else 256)
 
 
 def _as_i32(t):
@@ -44,7 +45,13 @@ class Schedule:
         cost = torch.where(is_seg, torch.zeros_like(deg), deg) + ROW_COST
         cum = torch.cumsum(cost, 0)
         total = int(cum[-1].item())
-        target = max(gpb * 16, min(gpb * 256, -(-total // MAX_BLOCKS_HINT)))
+        # Large operands: small blocks for narrow rows.  The workgroups resident on an XCD work on consecutive row blocks, so the
+        # rows they gather from -- for a graph with locality -- span (workgroups in flight) x (rows per block); with 256-cost blocks
+        # that window was 13 MB at C = 64 and thrashed the 4 MB L2 (banded 10 M-vertex graph: 30 GB fetched, 4.31 ms; with 64-cost
+        # blocks 3.02 ms).  No effect on graphs without locality (R-MAT: 4.35 vs 4.34 ms); rows wider than 64 floats keep the
+        # larger blocks (sheet mesh at C = 1200: 0.380 vs 0.398 ms).  tgcn_sched_build (csrc/graph_build.h) applies the same rule.
+        cap = BLOCK_ROWS_MAX if BLOCK_ROWS_MAX else (64 if lanes_per_row <= 16 else 256)
+        target = max(gpb * 16, min(gpb * cap, -(-total // MAX_BLOCKS_HINT)))
         nblk = max(1, -(-total // target))
         if nblk > 1:
             marks = torch.arange(1, nblk, device=dev, dtype=torch.int64) * target

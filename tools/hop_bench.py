@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seg-key", default="first")
     ap.add_argument("--only", default="all", choices=["all", "long", "short"], help="keep only the rows above / up to the row threshold (path analysis)")
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
+    ap.add_argument("--block-cost", type=int, default=None, help="graph.BLOCK_ROWS_MAX: entry-equivalents per lane group and row block (default 256)")
     ap.add_argument("--remap", default="1", help="comma list of hop_xcd_remap values, each crossed with the others")
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     args = ap.parse_args()
@@ -37,9 +38,13 @@ def main():
     if args.seg_len:
         graph.SEG_LEN = args.seg_len
     graph.SEG_KEY = args.seg_key
+    if args.block_cost:
+        graph.BLOCK_ROWS_MAX = args.block_cost
     dev = torch.device("cuda:0")
     if args.graph == "mesh":
         args.n, row, col, val = synth.sheet_mesh(300, device=dev)
+    elif args.graph == "banded":
+        _, row, col, val = synth.banded(args.n, args.nnz, device=dev)
     else:
         _, row, col, val = synth.rmat(args.n, args.nnz, labeling=args.labeling, device=dev)
     if args.only != "all":
@@ -80,7 +85,7 @@ def main():
     _lib.check(L.tgcn_set_tuning(b"hop_variant", 0))
     _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", 0))
     _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", 1))
-    alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph == 'rmat' else 1) + 8 * op.n * args.C
+    alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph in ('rmat', 'banded') else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
         print("variant %s: median %.3f ms  min %.3f ms   -> %.0f GB/s algorithmic (cfg5 accounting); fixup %.3f ms" % (v, np.median(t), t.min(), alg / np.median(t) / 1e6, np.median(fix[v])))

@@ -109,3 +109,18 @@ def grid_knn(side=28, device="cuda"):
     u, v = torch.cat(us), torch.cat(vs)
     row, col, val = normalized_laplacian_coo(n, torch.minimum(u, v), torch.maximum(u, v))
     return n, row, col, val
+
+
+def banded(n, nnz, width=4096, seed=12345, device="cuda"):
+    """Graph with the sizes of the R-MAT workload but perfect locality: every vertex has nnz/n neighbours drawn within +-width of
+    its own index (symmetrised, de-duplicated).  Upper bound for the hop kernel: the gathers of a row block hit in L2."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    m = nnz // 2
+    u = torch.randint(0, n, (int(m * 1.05),), device=device, generator=gen)
+    off = torch.randint(1, width + 1, (u.numel(),), device=device, generator=gen)
+    v = u + off
+    ok = v < n
+    keys = torch.unique(u[ok] * n + v[ok])[:m]
+    u, v = keys // n, keys % n
+    row, col, val = normalized_laplacian_coo(n, u, v)
+    return n, row, col, val
