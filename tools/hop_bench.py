@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seg-key", default="first")
     ap.add_argument("--only", default="all", choices=["all", "long", "short"], help="keep only the rows above / up to the row threshold (path analysis)")
     ap.add_argument("--split", type=int, default=1, help="process the C channels in this many column slices")
+    ap.add_argument("--fold-cols", type=int, default=None, help="replace every column c by c %% H spread over the table: the same row structure with all gathers inside an H-row hot set (upper bound of any locality scheme)")
     ap.add_argument("--block-cost", type=int, default=None, help="graph.BLOCK_ROWS_MAX: entry-equivalents per lane group and row block (default 256)")
     ap.add_argument("--remap", default="1", help="comma list of hop_xcd_remap values, each crossed with the others")
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
@@ -47,6 +48,8 @@ def main():
         _, row, col, val = synth.banded(args.n, args.nnz, device=dev)
     else:
         _, row, col, val = synth.rmat(args.n, args.nnz, labeling=args.labeling, device=dev)
+    if args.fold_cols:
+        col = (col % args.fold_cols) * (args.n // args.fold_cols)
     if args.only != "all":
         deg = torch.bincount(row, minlength=args.n)
         thr = args.row_thresh or graph.ROW_THRESH
