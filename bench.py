@@ -164,16 +164,17 @@ def torch_dense_baseline(op, spec, layer, x):
                              sample="whole batch, dense (n, n) einsum as the reference evaluates it (gcn.py:72-78,147-153,230-236), torch CPU, %d runs of %.1f ms" % (reps, dt * 1e3))
 
 
-def cpu_baseline(op, spec, layer, x, budget_q=1):
-    """oracle/cheb_ref.c (reference algorithm: full stack + unfolded weights) on the host cores, on `budget_q`
-    of the q samples of the same workload."""
+def cpu_baseline(op, spec, layer, x, samples=(0,)):
+    """oracle/cheb_ref.c (reference algorithm: full stack + unfolded weights) on the host cores, on the listed
+    samples (time steps) of the same workload."""
     from oracle import c_port
     row, col, val = op.coo()
     rowptr = op.rowptr.cpu().numpy()
     col = col.to(torch.int32).cpu().numpy()
     val = val.cpu().numpy()
-    q = min(budget_q, spec["q"])
-    xs = x[:q].reshape(q, op.n, -1).float().cpu().numpy()
+    samples = sorted(set(int(i) % spec["q"] for i in samples))
+    q = len(samples)
+    xs = np.stack([x[i].reshape(op.n, -1).float().cpu().numpy() for i in samples])
     K = spec["K"]
     W = layer.weight.detach().reshape(K, -1, spec["g"]).cpu().numpy()
     b = layer.bias.detach().reshape(-1).cpu().numpy()
@@ -183,7 +184,7 @@ def cpu_baseline(op, spec, layer, x, budget_q=1):
     dt = time.perf_counter() - t0
     units = op.nnz * (K - 1) * q * spec["H"]
     return out, dict(value=units / dt / 1e9, unit="G edge\u00b7timesteps/s", cores=c_port.threads(), kind="port",
-                     sample="%d of %d samples of the same workload, full K=%d forward, oracle/cheb_ref.c OpenMP, %.1f s" % (q, spec["q"], K, dt))
+                     sample="samples %s of the %d of the same workload, full K=%d forward, oracle/cheb_ref.c OpenMP, %.1f s" % (samples, spec["q"], K, dt))
 
 
 def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards):
@@ -214,7 +215,7 @@ def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards):
     return (lambda _x=None: sh.forward(x_local, Wf, bias_local, 2, 0)), sh, ngroups, q
 
 
-def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist):
+def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress=None):
     """Vertex-sharded and hybrid runs of the same workload (2 timed forwards each).  They must never cost the headline: every
     failure becomes an entry with an `error`, and if they overrun --extras-budget the caller's line is printed without them
     (the watchdog thread of every rank ends its process)."""
@@ -223,6 +224,8 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist):
     modes = [("vertex", world)] + ([("hybrid", 2)] if world >= 4 and world % 2 == 0 else [])
     for mode, vs in modes:
         entry = dict(shard=mode, vertex_shards=vs)
+        if progress is not None:
+            progress["mode"] = mode
         try:
             fwd, sh, ngroups, qg = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs)
             steps = 2
@@ -267,6 +270,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--project-variant", type=int, default=None, help="developer: tgcn_set_tuning(project_variant, v)")
     ap.add_argument("--no-small-path", action="store_true", help="developer: disable the one-launch small-graph kernel")
+    ap.add_argument("--compact-q-chunk", type=int, default=None, help="developer: time steps per pass of the compacted forward")
+    ap.add_argument("--no-compact", action="store_true", help="developer: hop tensors for all vertices even when many rows are empty")
     ap.add_argument("--no-extras", action="store_true", help="N > 1, time sharding: skip the vertex-sharded / hybrid runs reported in `other_shardings`")
     ap.add_argument("--extras-budget", type=float, default=150.0, help="seconds after which the extra runs are abandoned and the headline line is printed without them")
     args = ap.parse_args()
@@ -289,6 +294,9 @@ def main():
     from tgcn_amd import _lib, functional as _F
     if args.no_small_path:
         _F.SMALL_PATH = False
+    _F.COMPACT_Q_CHUNK = args.compact_q_chunk
+    if args.no_compact:
+        _F.COMPACT = False
     if args.project_variant is not None:
         _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", args.project_variant))
     op, spec = build_workload(args.workload, args.labeling, device, args.vertices, args.entries)
@@ -385,11 +393,12 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, args.labeling))
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("source_hash") == _lib.source_hash():
+            have = _lib.binary_hash()          # the stamp of the library that is loaded, not of the sources on disk
+            if tj.get("source_hash") == have:
                 traffic = tj.get("hbm_bytes_per_hop_launch")
                 traffic_note = "%s (source hash %s)" % (os.path.relpath(tpath, ROOT), tj.get("source_hash"))
             else:
-                traffic_note = "%s is from other kernel sources (%s, now %s): stale, not reported" % (os.path.relpath(tpath, ROOT), tj.get("source_hash"), _lib.source_hash())
+                traffic_note = "%s is from other kernel sources (%s, loaded binary %s): stale, not reported" % (os.path.relpath(tpath, ROOT), tj.get("source_hash"), have)
         copy_gbps = measured_copy_gbps(device)
         roofline = dict(bound="hbm", kernel="hop_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_note,
@@ -399,14 +408,23 @@ def main():
                         mean_launch_ms=round(mean_ms, 4), hop_ms_per_step=round(float(np.sum(hop_ms)) / args.steps, 3),
                         fixup_ms_per_step=round(float(np.sum(fix_ms)) / args.steps, 3),
                         project_ms_per_step=round(float(np.sum(proj_ms)) / args.steps, 3))
+        step_s = dt / args.steps
+        roofline["whole_step"] = dict(bytes=int(bytes_recursion), achieved=round(bytes_recursion / step_s / 1e9, 1), unit="GB/s",
+                                      frac=round(bytes_recursion / step_s / 1e9 / HBM_PEAK_GBPS, 4),
+                                      note="SURVEY 8(d) recursion bytes of one rank's forward / its whole forward time (hops + fix-up + projection)")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        ref_out, cpu = cpu_baseline(op, spec, layer, x)
-        got = out[: ref_out.shape[0]].cpu().numpy()
-        err = float(np.abs(got - ref_out).max() / np.abs(ref_out).max())
+        # first AND last sample: the last one sits behind (q-1)*n*C elements (> 2^31 on cfg5), so the check also covers the
+        # 64-bit address arithmetic of the run that was timed
+        check = [0, q - 1] if (q > 1 and op.n * C_row * q >= 2 ** 31) else [0]
+        ref_out, cpu = cpu_baseline(op, spec, layer, x, samples=check)
+        got = np.stack([out[i].cpu().numpy() for i in check])
+        errs = [float(np.abs(got[i] - ref_out[i]).max() / np.abs(ref_out[i]).max()) for i in range(len(check))]
+        err = max(errs)
         cpu["gpu_vs_cpu_rel_err"] = err
-        assert err <= 1e-5, "GPU result differs from the CPU restatement: %g" % err
+        cpu["checked_samples"] = check
+        assert err <= 1e-5, "GPU result differs from the CPU restatement: %s" % errs
         cpu["scipy_single_thread"] = scipy_baseline(op, spec, x)
         if op.n <= 4096 and spec["cls"] in ("GCNCheb", "TGCNCheb_H"):
             ref2, cpu["torch_dense_einsum"] = torch_dense_baseline(op, spec, layer, x)
@@ -414,6 +432,11 @@ def main():
             cpu["torch_dense_einsum"]["gpu_vs_cpu_rel_err"] = err2
             assert err2 <= 1e-5, "GPU result differs from the dense-L einsum restatement: %g" % err2
 
+    # what the arithmetic of this run was (the label of `dtype`): hops and accumulators are fp32 throughout; large projections
+    # take the bf16 matrix pipe with every fp32 operand split three ways (fp32-equivalent)
+    plan = None if vertex_mode else (op.compact_plan() if (_F.COMPACT and spec["cls"] in ("TGCNCheb", "TGCNCheb_H", "GCNCheb") and not small_ms and not pf_path
+                                                           and 2 <= K <= 32 and _F.choose_layout(q, op.n, C_row) == 0) else None)
+    x3_proj = (not small_ms) and op.n * max(q, 1) >= 8192 and C_row * K >= 64 and (args.project_variant in (None, 0, 3))
     line = None
     if rank == 0:
         line = dict(metric=baseline_metric(), value=round(value, 3), unit="G edge\u00b7timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -421,26 +444,39 @@ def main():
                     dtype="f32", data="synthetic",
                     config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
                                 sharding=(("%d group(s) x %d vertex shards, %s exchange per hop inside a group" % (ngroups, sh.world, sh.exchange)) if ngroups > 1 else ("vertex rows across ranks, %s exchange per hop" % sh.exchange)) if vertex_mode else (("the %d time steps of the workload split over %d ranks (%d on rank 0), CSR replicated, no collective" % (q_total, world, q) if strong_time else "%d time steps per rank, CSR replicated, no collective" % q) if world > 1 else "single GPU"),
-                                nnz=op.nnz, n=op.n),
+                                nnz=op.nnz, n=op.n,
+                                arithmetic="f32 (bf16x3 projection: fp32 operands split into three bf16 terms on the matrix pipe)" if x3_proj else "f32",
+                                empty_rows=(plan.n_empty if plan is not None else 0),
+                                hop_tensors="compact (%d of %d vertices have stored entries)" % (plan.n_c, op.n) if plan is not None else "all vertices"),
                     roofline=roofline, cpu_baseline=cpu)
     # ---- N > 1: the mandated vertex-sharded scheme (and the hybrid grid) on the same workload, reported next to the headline.
     # A watchdog on every rank prints the headline without them and ends the process if they overrun their budget.
     if world > 1 and args.shard == "time" and not args.no_extras and spec["cls"] in ("TGCNCheb", "TGCNCheb_H"):
         import threading
+        printed = threading.Lock()         # exactly one JSON line, whoever gets there first
+        progress = dict(mode=None)
 
         def bail():
+            # a stalled exchange (or a GPU hang) in the extras: the headline is still valid, so print it -- marked -- and end every
+            # rank with a non-zero code so that the driver sees from rc that something stalled (plain exit, never a re-exec)
+            if not printed.acquire(blocking=False):
+                return
             if rank == 0:
-                line["other_shardings"] = [dict(error="abandoned after %.0f s (--extras-budget)" % args.extras_budget)]
+                line["extras_abandoned"] = True
+                line["other_shardings"] = [dict(error="abandoned after %.0f s (--extras-budget)" % args.extras_budget, last_started=progress["mode"])]
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
         dog = threading.Timer(args.extras_budget, bail)
         dog.daemon = True
         dog.start()
-        extras = run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist)
+        extras = run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress)
         dog.cancel()
+        if not printed.acquire(blocking=False):      # the watchdog fired while the extras were returning: it prints and exits
+            time.sleep(3600)
         if rank == 0:
             line["other_shardings"] = extras
-    if rank == 0:
+            print(json.dumps(line), flush=True)
+    elif rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

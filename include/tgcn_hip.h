@@ -30,7 +30,7 @@ extern "C" {
 #define TGCN_ERR_WORKSPACE (-3)   /* caller workspace too small */
 #define TGCN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
 
-#define TGCN_ABI_VERSION 3
+#define TGCN_ABI_VERSION 4
 
 /* One stored entry of the sparse operand: 8 bytes, read with a single load. */
 typedef struct tgcn_edge {
@@ -56,7 +56,10 @@ typedef struct tgcn_csr {
  *   gather from the same region of the dense operand at about the same time (hub columns then hit in L2).
  *   A segment that is its whole row writes the row directly (seg_slot = -1); rows cut into several segments
  *   ("long rows") sum them through numbered scratch slots that a fix-up launch folds in slot order, so results
- *   do not depend on timing.  The first nhuge long rows (most slots) get a whole workgroup each in the fix-up. */
+ *   do not depend on timing.  The first nhuge long rows (most slots) get a whole workgroup each in the fix-up.
+ *   seg_mode 0: one lane group per segment (segments of <= 32 entries).  seg_mode 1 (lanes_per_row < 64): one WAVE per
+ *   segment of <= 32 * (64 / lanes_per_row) entries -- its lane groups take consecutive pieces and the pieces are folded
+ *   inside the wave, so rows up to that length are written directly and longer rows leave one partial row per wave. */
 typedef struct tgcn_csr_sched {
   int32_t lanes_per_row; /* lane-group width the schedule was balanced for: 1,2,4,...,64 */
   int32_t row_thresh;
@@ -65,7 +68,7 @@ typedef struct tgcn_csr_sched {
   int32_t nlong;    /* rows cut into more than one segment */
   int32_t nhuge;    /* leading entries of long_row folded by a whole workgroup */
   int32_t npartial; /* scratch slots (= segments of long rows) */
-  int32_t reserved;
+  int32_t seg_mode; /* 0 lane-group segments, 1 wave segments */
   const int32_t* blk_row;   /* [nblk+1] first row of each block; blk_row[nblk] == n */
   const int32_t* seg_row;   /* [nseg] */
   const int32_t* seg_e0;    /* [nseg] first entry */
@@ -139,6 +142,7 @@ int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* coun
  * tests/test_fuzz_parity.py).  Process-wide, same arithmetic, another kernel; returns TGCN_ERR_INVALID for unknown keys.
  *   "hop_variant"     0 shipped hop kernel; 1.. alternative unroll / row-interleave shapes of hop.h
  *   "hop_xcd_remap"   1 (default): each XCD gets a contiguous range of row blocks; 0: row blocks round robin over the XCDs
+ *   "hop_seg_remap"   1: each XCD gets a contiguous range of the column-ordered segment blocks; 0 (default): round robin
  *   "hop_lds_pad"     bytes of unused dynamic LDS per hop_kernel workgroup: limits the workgroups per CU to 160 KB / pad (0: none)
  *   "project_variant" 0 auto; 1 exact-fp32 streaming-W; 2 exact-fp32 W-resident with 16-row wave tiles; 3 bf16x3 always;
  *                     4 exact-fp32 auto; 5 vector-ALU narrow kernel wherever it applies
@@ -235,6 +239,22 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
                           int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
                           const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
                           void* workspace, size_t workspace_bytes);
+
+/* The same layer (mode 0 only) for operands with structurally EMPTY rows (R-MAT: 5.27 M of 10 M vertices; the isolated
+ * fake vertices the reference's coarsening pads its graphs with, gcn/coarsening.py:167-217).  For such a vertex i every hop
+ * tensor row P_k[i], k >= 1, is zero, so out[i] = x[i] W_0 + bias[i]; the hop tensors are kept for the n_c vertices that do
+ * have entries only (compact ids = rank among them):
+ *   A_first  n_c rows, columns in the caller's labels (hop 1 gathers from x);  A_rest  the same rows and entry order with
+ *            columns in compact ids, entries whose column is an empty vertex pointing at the zero row n_c  (hops 2..K-1);
+ *   rows[n_c] / empty_rows[n_empty]  caller's label of every compact / empty row, ascending;  sched: shared by both operands.
+ * The projection reads x, bias and writes out through the row maps; hop tensors, hop writes and four of the five projection
+ * terms shrink by n_empty / n.  Bitwise equal to tgcn_cheb_forward_f32 (layout 0) on the same operand.  K >= 2. */
+size_t tgcn_cheb_forward_compact_workspace_bytes(const tgcn_csr_sched* sched, int32_t K, int64_t q, int64_t n_c, int32_t C,
+                                                 int64_t q_chunk);
+int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const tgcn_csr* A_rest, const tgcn_csr_sched* sched,
+                                  int32_t K, int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
+                                  const float* bias, int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows,
+                                  int64_t n_empty, int64_t q_chunk, void* workspace, size_t workspace_bytes);
 
 /* "Project first" form of the same layer for wide inputs and narrow outputs (N well below C = H*f, e.g.
  * TGCNCheb_H(L, 1, 32, K, 1200)): Z = x . Wcat for all K terms in ONE projection (Wcat: C x (K*N), column block j =

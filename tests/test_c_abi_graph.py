@@ -108,7 +108,7 @@ def test_library_schedule_equals_the_python_builder(lib, n):
         _ok(lib, lib.tgcn_sched_build(g, C.c_int32(C_row), C.c_int(1), C.byref(s)))
         mine = C.cast(lib.tgcn_sched_get(s), C.POINTER(SchedStruct)).contents
         py = op.schedule_for(C_row, True)
-        for f in ("lanes_per_row", "row_thresh", "nblk", "nseg", "nlong", "nhuge", "npartial"):
+        for f in ("lanes_per_row", "row_thresh", "nblk", "nseg", "nlong", "nhuge", "npartial", "seg_mode"):
             assert getattr(mine, f) == getattr(py.struct, f), f
         for f, cnt in (("blk_row", py.nblk + 1), ("seg_row", py.nseg), ("seg_e0", py.nseg), ("seg_e1", py.nseg), ("seg_slot", py.nseg),
                        ("long_row", py.nlong), ("long_slot", py.nlong + 1)):

@@ -1,0 +1,204 @@
+"""Round-3 kernels of the large-graph path, through the C ABI, against the oracle:
+  * wave segments (tgcn_csr_sched.seg_mode 1): the lane groups of a wave share one segment of a long row and fold their pieces
+    inside the wave -- against lane-group segments (seg_mode 0) and the oracle, on rows around every length boundary;
+  * compacted forward (tgcn_cheb_forward_compact_f32): hop tensors only for the vertices that have stored entries -- against
+    the plain forward of the same operand (bitwise with one projection kernel) and against oracle/cheb_ref.c.
+Tolerance: max|a-b| / max|b| <= 1e-5 per tensor, fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, golden_ids, load_golden, rel_err
+from oracle import cheb_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _graph_with_rows(n, lengths, rng, base_deg=5, empty=()):
+    """random graph: `base_deg` entries per row, row i of `lengths` (dict row -> entries) overwritten, `empty` rows left empty"""
+    deg = np.full(n, base_deg)
+    for r, d in lengths.items():
+        deg[r] = d
+    deg[list(empty)] = 0
+    row = np.repeat(np.arange(n), deg)
+    col = rng.integers(0, n, row.shape[0])
+    val = (rng.standard_normal(row.shape[0]) / 4).astype(np.float32)
+    return row, col, val
+
+
+@pytest.mark.parametrize("C", [64, 16, 100, 8, 1])
+def test_wave_segments_vs_oracle_and_group_segments(C, gpu_device, monkeypatch):
+    from tgcn_amd import functional as F, graph, _lib
+    n = 30000
+    rng = np.random.default_rng(C)
+    lanes = _lib.lib().tgcn_hop_lanes_per_row(C, 1)
+    wave_len = 32 * (64 // lanes)
+    lengths = {3: 33, 17: wave_len - 1, 18: wave_len, 19: wave_len + 1, 40: 2 * wave_len, 41: 3 * wave_len + 5, 900: 64 * wave_len + 7,
+               901: 20000, 29999: 700, 12: 32, 13: 1}
+    row, col, val = _graph_with_rows(n, lengths, rng, empty=(0, 7, 15000))
+    L = O.coo_to_csr(row, col, val, n)
+    x = rng.standard_normal((2, n, C)).astype(np.float32)
+    z = rng.standard_normal((2, n, C)).astype(np.float32)
+    ref = O._apply(L, x)
+    outs = {}
+    for mode in (0, 1):
+        monkeypatch.setattr(graph, "SEG_MODE", mode)
+        op = graph.GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+        s = op.schedule_for(C, C % 4 == 0)
+        assert s.seg_mode == (mode if s.lanes_per_row < 64 else 0)
+        if mode == 1 and s.lanes_per_row < 64:
+            assert s.seg_len == 32 * (64 // s.lanes_per_row) and s.nhuge >= 1 and s.nlong >= 4
+        y, p = F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0, want_p=True)
+        assert rel_err(p.cpu().numpy(), ref) <= TOL
+        assert rel_err(y.cpu().numpy(), 2 * ref - z) <= TOL
+        assert np.array_equal(y.cpu().numpy()[:, 7], -z[:, 7])
+        assert torch.equal(y, F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0))      # run-to-run determinism
+        # segment blocks in XCD-contiguous ranges: another place, the same sums
+        _lib.check(_lib.lib().tgcn_set_tuning(b"hop_seg_remap", 1))
+        try:
+            assert torch.equal(y, F.csr_hop(op, _dev(x), z=_dev(z), alpha=2.0, beta=-1.0))
+        finally:
+            _lib.check(_lib.lib().tgcn_set_tuning(b"hop_seg_remap", 0))
+        outs[mode] = p
+    # rows that are ONE segment in both modes are summed in the same order
+    short = np.array([r for r in range(n) if L.indptr[r + 1] - L.indptr[r] <= 32])
+    assert torch.equal(outs[0][:, short], outs[1][:, short])
+
+
+def _rmat_like(n, m, rng, symmetric=True):
+    """skewed graph with many isolated vertices: endpoints drawn from a power law over a random relabelling"""
+    perm = rng.permutation(n)
+    u = perm[np.minimum((rng.random(m) ** 4 * n).astype(np.int64), n - 1)]
+    v = perm[np.minimum((rng.random(m) ** 4 * n).astype(np.int64), n - 1)]
+    keep = u != v
+    u, v = u[keep], v[keep]
+    if symmetric:
+        row, col = np.concatenate([u, v]), np.concatenate([v, u])
+    else:
+        row, col = u, v
+    val = (rng.standard_normal(row.shape[0]) / 6).astype(np.float32)
+    return row, col, val
+
+
+@pytest.mark.parametrize("symmetric", [True, False], ids=["symmetric", "entries-into-empty-rows"])
+@pytest.mark.parametrize("q,C,N,K,bias_kind", [(3, 64, 64, 5, 2), (2, 32, 48, 3, 1), (1, 20, 8, 2, 0), (2, 64, 64, 6, 2)])
+def test_compact_forward_equals_plain_forward(q, C, N, K, bias_kind, symmetric, gpu_device, monkeypatch):
+    from tgcn_amd import functional as F, graph, _lib
+    from oracle import c_port
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    n = 40000
+    rng = np.random.default_rng(q * 100 + C + K)
+    row, col, val = _rmat_like(n, 50000, rng, symmetric)
+    op = graph.GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    plan = op.compact_plan()
+    assert plan is not None and plan.n_c + plan.n_empty == n and plan.n_empty > n // 8
+    deg = np.bincount(row, minlength=n)
+    assert np.array_equal(plan.rows.cpu().numpy(), np.flatnonzero(deg > 0)) and np.array_equal(plan.empty.cpu().numpy(), np.flatnonzero(deg == 0))
+    if not symmetric:      # some entries point at vertices without outgoing entries: they must gather the zero row
+        assert (deg[col] == 0).any()
+    x = _dev(rng.standard_normal((q, n, C)).astype(np.float32))
+    W = _dev((rng.standard_normal((K, C, N)) / np.sqrt(K * C)).astype(np.float32))
+    bias = None if bias_kind == 0 else _dev(rng.standard_normal((N,) if bias_kind == 1 else (n, N)).astype(np.float32))
+    Wt = F.fold_weight(F.power_fold_matrix(K, x.device), W) if K > 2 else W
+    W2 = Wt.reshape(K * C, N).contiguous()
+    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 4))      # one (exact fp32) projection kernel for both: bitwise comparable
+    try:
+        plain = F.cheb_forward_raw(op, x, W2, bias, bias_kind, F.MODE_POWER, K, layout=0, q_chunk=1)
+        comp = F.cheb_forward_compact(plan, x, W2, bias, bias_kind, K, q_chunk=1)
+        comp2 = F.cheb_forward_compact(plan, x, W2, bias, bias_kind, K, q_chunk=2)
+    finally:
+        _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 0))
+    assert torch.equal(plain, comp) and torch.equal(comp, comp2)
+    # default kernels, through the dispatcher, against the C restatement of the reference's algorithm (unfolded weights)
+    out = F.layer_forward(op, x, W, F.power_fold_matrix(K, x.device) if K > 2 else None, bias, bias_kind, F.MODE_POWER)
+    rowptr = op.rowptr.cpu().numpy()
+    e = op.edges.cpu().numpy()
+    b = np.zeros(1, np.float32) if bias is None else bias.reshape(-1).cpu().numpy()
+    ref = c_port.forward(0, rowptr, np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1]).view(np.float32), x.cpu().numpy(),
+                         W.cpu().numpy(), b, bias_kind)
+    assert rel_err(out.cpu().numpy(), ref) <= TOL
+
+
+def test_compact_plan_is_declined_without_empty_rows(gpu_device, monkeypatch):
+    from tgcn_amd import graph
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    n = 5000
+    row = np.repeat(np.arange(n), 3)
+    col = (row + np.tile([1, 2, 3], n)) % n
+    op = graph.GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(np.ones(row.shape[0], np.float32)))
+    assert op.compact_plan() is None
+
+
+_PAD = [p for p in golden_files("") if "pad48" in p and ("GCNCheb_" in p or "TGCNCheb" in p)]
+
+
+@pytest.mark.parametrize("path", _PAD, ids=golden_ids(_PAD))
+def test_compact_forward_on_padded_fixtures(path, gpu_device, monkeypatch):
+    """the reference's own case of isolated vertices: coarsening pads graphs with fake vertices (gcn/coarsening.py:167-217);
+    fixtures *_pad48_* carry 48 of them.  Forced through the compacted general path, against the reference's output."""
+    from tgcn_amd import functional as F, graph
+    from test_hip_parity import _make_layer
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    monkeypatch.setattr(graph, "COMPACT_MIN_EMPTY", 0.0)
+    monkeypatch.setattr(F, "SMALL_PATH", False)
+    monkeypatch.setattr(F, "PROJECT_FIRST", False)
+    monkeypatch.setattr(F, "choose_layout", lambda q, n, C_row: 0)      # the compacted path works on the (q, n, C) layout
+    g = load_golden(path)
+    layer, extra = _make_layer(g)
+    x = _dev(g["x"])
+    used = []
+    real = F.cheb_forward_compact
+    monkeypatch.setattr(F, "cheb_forward_compact", lambda *a, **k: (used.append(1), real(*a, **k))[1])
+    with torch.no_grad():        # inference: a training forward keeps the full-label hop tensors for its backward instead
+        out = layer(x, *extra)
+    assert rel_err(out.detach().cpu().numpy(), g["out"]) <= TOL
+    if layer.weight.shape[0] >= 2:
+        assert used, "the compacted path was not taken"
+
+
+def test_offsets_beyond_2_31_elements(gpu_device):
+    """batch * n * C > 2^31 elements through the layer driver with q_chunk = 1 (the shape of the headline run: sample t of cfg5 sits
+    t * 640 M floats into x and out).  Size-independent properties, all compared on the device:
+      * the last sample computed inside the batch == the same sample computed alone at offset 0 (bitwise: same kernels, samples
+        are independent), for the plain and for the compacted forward;
+      * plain and compacted forward agree; linearity of the layer without bias on the last sample."""
+    from tgcn_amd import functional as F, graph, _lib
+    g = torch.Generator(device="cuda").manual_seed(9)
+    q, n, C, N, K = 9, 4_000_000, 64, 64, 3
+    assert q * n * C > 2 ** 31
+    m = 20_000_000
+    live = n // 2                                                  # the other half of the vertices keeps no entry
+    u = (torch.rand(m, device="cuda", generator=g) ** 3 * live).long().clamp_(max=live - 1)
+    v = (torch.rand(m, device="cuda", generator=g) ** 3 * live).long().clamp_(max=live - 1)
+    perm = torch.randperm(n, device="cuda", generator=g)
+    row, col = torch.cat([perm[u], perm[v]]), torch.cat([perm[v], perm[u]])
+    val = torch.randn(row.numel(), device="cuda", generator=g) * 0.05
+    op = graph.GraphOperand.from_coo(n, row, col, val)
+    del row, col, val, u, v
+    plan = op.compact_plan()
+    assert plan is not None and plan.n_empty > n // 8
+    x = torch.randn(q, n, C, device="cuda", generator=g)
+    W = torch.randn(K * C, N, device="cuda", generator=g) / (K * C) ** 0.5
+    bias = torch.randn(n, N, device="cuda", generator=g)
+    for fwd in (lambda xx, b, k: F.cheb_forward_raw(op, xx, W, b, k, F.MODE_POWER, K, layout=0, q_chunk=1),
+                lambda xx, b, k: F.cheb_forward_compact(plan, xx, W, b, k, K, q_chunk=1)):
+        full = fwd(x, bias, 2)
+        for t in (0, q - 1):
+            alone = fwd(x[t:t + 1].clone(), bias, 2)
+            assert torch.equal(full[t], alone[0]), "sample %d differs when computed inside the batch" % t
+        last = full[q - 1].clone()
+        del full, alone
+        if "ref_last" not in locals():
+            ref_last = last
+        else:
+            assert float((last - ref_last).abs().max() / ref_last.abs().max()) <= 1e-6
+    # linearity on the last sample: A(0.5 a + b) = 0.5 A a + A b
+    a, b = x[q - 1:q], x[0:1]
+    lhs = F.cheb_forward_compact(plan, 0.5 * a + b, W, None, 0, K)
+    rhs = 0.5 * F.cheb_forward_compact(plan, a.clone(), W, None, 0, K) + F.cheb_forward_compact(plan, b.clone(), W, None, 0, K)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= TOL

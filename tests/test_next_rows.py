@@ -159,3 +159,33 @@ def test_reordered_operand_is_permutation_invariant(kind, cls, gpu_device):
     assert rel_err(stack.cpu().numpy(), O.stack_reference_power(L, x, la.filter_order)) <= TOL
     z = tgcn_amd.cheb_relu_pool(lb, _dev(x), pool=2)
     assert rel_err(z.cpu().detach().numpy(), O.gcn_pool(np.maximum(want, 0), 2)) <= TOL
+
+
+@pytest.mark.parametrize("kind", ["degree", "rcm"])
+def test_reordered_operand_in_forward_series_and_to(kind, gpu_device):
+    """a reordered operand must stay one through forward_series (hops of the streaming-window layer, both directions)
+    and through GraphOperand.to(): same outputs and gradients in the caller's labels as the plain operand."""
+    import tgcn_amd
+    rng = np.random.default_rng(5)
+    n, S, T, H, g, K = 700, 2, 24, 6, 5, 4
+    row, col = _sym_graph(n, 6, rng)
+    val = (rng.standard_normal(row.shape[0]) / 4).astype(np.float32)
+    op = tgcn_amd.GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    opr = op.reordered(kind)
+    moved = opr.to("cuda:0")
+    assert moved.perm is not None and torch.equal(moved.perm, opr.perm) and torch.equal(moved.inv_perm, opr.inv_perm)
+    assert abs(moved.to_scipy() - opr.to_scipy()).max() == 0
+    torch.manual_seed(3)
+    la = tgcn_amd.TGCNCheb_H(op, 1, g, K, H).cuda()
+    lb = tgcn_amd.TGCNCheb_H(moved, 1, g, K, H).cuda()
+    lb.load_state_dict(la.state_dict())
+    series = rng.standard_normal((S, n, T)).astype(np.float32)
+    sa, sb = _dev(series).requires_grad_(True), _dev(series).requires_grad_(True)
+    oa, ob = la.forward_series(sa), lb.forward_series(sb)
+    assert rel_err(ob.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= TOL
+    go = torch.randn_like(oa)
+    oa.backward(go)
+    ob.backward(go)
+    assert rel_err(sb.grad.cpu().numpy(), sa.grad.cpu().numpy()) <= 2e-5
+    assert rel_err(lb.weight.grad.cpu().numpy(), la.weight.grad.cpu().numpy()) <= 2e-5
+    assert rel_err(lb.bias.grad.cpu().numpy(), la.bias.grad.cpu().numpy()) <= 2e-5

@@ -22,7 +22,7 @@ class CsrStruct(C.Structure):
 
 class SchedStruct(C.Structure):
     _fields_ = [("lanes_per_row", C.c_int32), ("row_thresh", C.c_int32), ("nblk", C.c_int32), ("nseg", C.c_int32),
-                ("nlong", C.c_int32), ("nhuge", C.c_int32), ("npartial", C.c_int32), ("reserved", C.c_int32),
+                ("nlong", C.c_int32), ("nhuge", C.c_int32), ("npartial", C.c_int32), ("seg_mode", C.c_int32),
                 ("blk_row", C.c_void_p), ("seg_row", C.c_void_p), ("seg_e0", C.c_void_p), ("seg_e1", C.c_void_p),
                 ("seg_slot", C.c_void_p), ("long_row", C.c_void_p), ("long_slot", C.c_void_p)]
 
@@ -77,6 +77,10 @@ SIGNATURES = {
     "tgcn_cheb_forward_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
                                         C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P,
                                         C.c_int32, C.c_int64, _P, C.c_size_t]),
+    "tgcn_cheb_forward_compact_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64]),
+    "tgcn_cheb_forward_compact_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32,
+                                                C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P,
+                                                C.c_int64, C.c_int64, _P, C.c_size_t]),
     "tgcn_cheb_forward_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_basis_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_forward_small_pool_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
@@ -111,6 +115,15 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def binary_hash():
+    """source hash recorded next to the library when it was built (LIB_PATH.srchash): names the code of the BINARY that lib()
+    loads, which is what a committed counter file has to match -- the sources on disk may have moved on"""
+    try:
+        return open(LIB_PATH + ".srchash").read().strip()
+    except OSError:
+        return None
+
+
 def build(verbose=False, force=False):
     """Compile the HIP sources for gfx950 into tgcn_amd/lib/libtgcn_hip.so (hipcc cross-compiles without a GPU).
     force=False reuses a library whose recorded source hash matches the sources (modification times say nothing about a
@@ -121,7 +134,7 @@ def build(verbose=False, force=False):
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = LIB_PATH + ".tmp"
+    tmp = LIB_PATH + ".%d.tmp" % os.getpid()      # per process: concurrent builders must not share a half-written file
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-I", INCLUDE, "-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd))
@@ -142,7 +155,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.tgcn_abi_version() != 3:
+        if handle.tgcn_abi_version() != 4:
             raise TgcnError("tgcn_amd: ABI version mismatch")
         _lib = handle
     return _lib

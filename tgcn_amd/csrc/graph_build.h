@@ -137,7 +137,8 @@ int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched**
   const int lanes = hop_geom(C, aligned16).lpr;
   const int gpb = kBlock / lanes;
   const int64_t n = g->csr.n;
-  const int32_t row_thresh = 32, seg_len = 32, huge_slots = 64, row_cost = 4;
+  const int32_t seg_mode = 0;                             // lane-group segments, as tgcn_amd/graph.py::SEG_MODE (wave segments measured slower on cfg5)
+  const int32_t row_thresh = 32, seg_len = seg_mode == 1 ? 32 * (64 / lanes) : 32, huge_slots = 64, row_cost = 4;
   const int64_t max_blocks_hint = 2048;
   const std::vector<int32_t>& rp = g->h_rowptr;
   // ---- short rows: nnz-balanced row blocks (cost = entries + 4 per row; long rows cost 4)
@@ -204,7 +205,7 @@ int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched**
   }
   memset(&sc->s, 0, sizeof(sc->s));
   sc->s.lanes_per_row = lanes; sc->s.row_thresh = row_thresh; sc->s.nblk = (int32_t)nblk; sc->s.nseg = (int32_t)nseg;
-  sc->s.nlong = (int32_t)nlong; sc->s.nhuge = (int32_t)nhuge; sc->s.npartial = (int32_t)npartial;
+  sc->s.nlong = (int32_t)nlong; sc->s.nhuge = (int32_t)nhuge; sc->s.npartial = (int32_t)npartial; sc->s.seg_mode = seg_mode;
   sc->s.blk_row = (const int32_t*)sc->blk_row.p; sc->s.seg_row = (const int32_t*)sc->seg_row.p; sc->s.seg_e0 = (const int32_t*)sc->seg_e0.p;
   sc->s.seg_e1 = (const int32_t*)sc->seg_e1.p; sc->s.seg_slot = (const int32_t*)sc->seg_slot.p; sc->s.long_row = (const int32_t*)sc->long_row.p;
   sc->s.long_slot = (const int32_t*)sc->long_slot.p;

@@ -25,6 +25,7 @@ struct HopParams {
   float alpha, beta, gamma;
   int32_t nblk, nseg, nlong, nhuge, row_thresh;
   int32_t C, nb, nchunks, cpad, remap;
+  int32_t seg_mode, seg_remap;   // seg_mode 1: one WAVE per segment (tgcn_csr_sched.seg_mode); seg_remap: XCD-contiguous segment ranges
 };
 
 template <int VEC>
@@ -233,7 +234,42 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
         if (live[rr] && cact) finish_row<VEC, NTM>(p, b, rb + rr * GPB, c0, acc[rr]);
     }
   } else {
-    const int sb = (bid - p.nblk) * GPB * R + gib;
+    int sbid = bid - p.nblk;
+    if (p.seg_remap) sbid = xcd_remap(sbid, (int)gridDim.x - p.nblk);
+    if constexpr (LPR < 64 && R == 1) {
+      if (p.seg_mode == 1) {
+        // One wave per segment of up to 32 * (64 / LPR) entries: its lane groups take consecutive pieces of the segment and the
+        // pieces are folded inside the wave (fixed order: neighbours first), so a row of up to that many entries is written
+        // directly and longer rows leave one partial row per wave instead of one per lane group.
+        constexpr int GPW = 64 / LPR;
+        const int s = sbid * (kBlock / 64) + (tid >> 6);
+        const int gw = (tid & 63) / LPR;
+        int e0[1] = {0}, e1[1] = {0};
+        if (s < p.nseg) {
+          const int a = p.seg_e0[s], z = p.seg_e1[s];
+          const int per = (z - a + GPW - 1) / GPW;
+          e0[0] = min(z, a + gw * per);
+          e1[0] = min(z, e0[0] + per);
+        }
+        float acc[1][VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[0][i] = 0.f;
+        accum_multi<LPR, VEC, UU, 1, NTM>(p.ev, e0, e1, t, Xc, p.x_ld, acc);
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[0][i] += __shfl_xor(acc[0][i], off, 64);
+        if (s >= p.nseg || gw != 0) return;
+        const int slot = p.seg_slot[s];
+        if (slot < 0) {
+          if (cact) finish_row<VEC, NTM>(p, b, p.seg_row[s], c0, acc[0]);
+        } else {
+          store_vec<VEC>(p.partial + ((int64_t)slot * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc[0]);
+        }
+        return;
+      }
+    }
+    const int sb = sbid * GPB * R + gib;
     int e0[R], e1[R];
     float acc[R][VEC];
 #pragma unroll
@@ -333,7 +369,8 @@ inline HopGeom hop_geom(int32_t C, int aligned16) {
 template <int LPR, int VEC, int U, int R, int NTM = 0>
 inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
   constexpr int GPB = kBlock / LPR;
-  grid.x = (unsigned)(p.nblk + (p.nseg + GPB * R - 1) / (GPB * R));
+  const int seg_per_block = (p.seg_mode == 1 && LPR < 64 && R == 1) ? kBlock / 64 : GPB * R;
+  grid.x = (unsigned)(p.nblk + (p.nseg + seg_per_block - 1) / seg_per_block);
   // "hop_lds_pad": unused dynamic LDS per workgroup = an occupancy limiter (160 KB / pad workgroups per CU) for A/B runs
   const int pad = g_hop_lds_pad.load();
   if (pad > 65536) allow_large_lds((const void*)hop_kernel<LPR, VEC, U, R, NTM>, pad);

@@ -17,7 +17,30 @@ struct ProjParams {
   int32_t Kc, N, nterms, bias_kind, accumulate, vec_epilogue;
   int32_t bias_ld, bias_cols;   // bias row length and number of leading output columns that receive it
   int32_t win_n, win_t;   // > 0: row m of A_t is the window starting at A_t[(m / win_n) * win_t + (m % win_n)]
+  // Row map (compacted operands: the hop tensors hold only the vertices that have stored entries): tile row m is the
+  // caller's vertex rowmap[m] -- its output row, its bias row, and its row in every term whose bit is set in `mapped`
+  // (term 0 = x in the caller's labels); the other terms are read at row m.
+  const int32_t* rowmap;
+  uint32_t mapped;
+  // Batch of samples sharing the tile rows (project_x3_kernel<NT, true> only; the host loops for the other kernels): sample b
+  // reads term t at a[t] + b * a_bs[t] and writes out + b * out_bs.  Consecutive workgroups take the SAME tile for the nbatch
+  // samples, so they run at about the same time and the tile's per-vertex bias rows reach HBM once -- the other samples find
+  // them in the Infinity Cache (cfg5: 2.56 GB of bias per time step otherwise).  Keeping the bias tile in registers across an
+  // in-kernel sample loop instead cost 32 VGPRs and half the occupancy (projection 45 -> 71 ms per forward).
+  int32_t nbatch;
+  int64_t a_bs[kMaxTerms];
+  int64_t out_bs;
 };
+
+// row of term `term` that tile row m reads
+__device__ __forceinline__ int64_t proj_arow(const ProjParams& p, int term, int64_t m) {
+  return (p.rowmap && ((p.mapped >> term) & 1u)) ? (int64_t)p.rowmap[m] : m;
+}
+// output row of tile row m: the row map, or the layout-1 interleave (vertex-major tile rows -> sample-major output)
+__device__ __forceinline__ int64_t proj_orow(const ProjParams& p, int64_t m) {
+  if (p.rowmap) return (int64_t)p.rowmap[m];
+  return (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+}
 
 // float offset of row m of a term: plain row stride, or overlapping time windows of a (vertex, T) series
 __device__ __forceinline__ int64_t proj_row_off(const ProjParams& p, int64_t m, int64_t lda) {
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
         const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
         const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
         const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
-        const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+        const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rr) * lda + kc);
         ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
       }
     } else {
@@ -72,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
         const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
         const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
         const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
-        const float v = A[proj_row_off(p, rr, lda) + kc];
+        const float v = A[proj_row_off(p, proj_arow(p, term, rr), lda) + kc];
         ra[h] = ok ? v : 0.f;
       }
     }
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const ProjParams p) {
     for (int i = 0; i < 4; ++i) {
       const int64_t m = m0 + wave * 32 + r * 16 + (lane >> 4) * 4 + i;
       if (m >= p.M) continue;
-      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t orow = proj_orow(p, m);
       const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -183,8 +206,10 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
   __shared__ __align__(16) unsigned short Ap[3][BM * RS];
   __shared__ __align__(16) unsigned short Wp[3][NW * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int bb = (int)(blockIdx.x % (unsigned)p.nbatch);          // sample of the batch: consecutive workgroups share a tile
+  const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)p.nbatch) * BM;
   const int n0 = blockIdx.y * NW;
+  float* const outb = p.out + (int64_t)bb * p.out_bs;
   f32x4 acc[2][NT];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -196,7 +221,7 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
   float ra[16], rw[2 * WPAIRS];
   auto load_tile = [&](int ti) {
     const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
-    const float* __restrict__ A = p.a[term];
+    const float* __restrict__ A = p.a[term] + (int64_t)bb * p.a_bs[term];
     const int64_t lda = p.lda[term];
     const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
     if constexpr (VEC4) {
@@ -206,7 +231,7 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
         const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
         const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
         const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
-        const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+        const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rr) * lda + kc);
         ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
       }
     } else {      // thread = (row, k pair)
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const bool ok = (m0 + row < p.M) && (k0 + kk + j < p.Kc);
-          const float v = A[proj_row_off(p, rr, lda) + (ok ? k0 + kk + j : 0)];
+          const float v = A[proj_row_off(p, proj_arow(p, term, rr), lda) + (ok ? k0 + kk + j : 0)];
           ra[h * 2 + j] = ok ? v : 0.f;
         }
       }
@@ -329,13 +354,13 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
           const int col = n0 + seg;
           if (m >= p.M || col >= p.N) continue;
           float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
-          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          const int64_t orow = proj_orow(p, m);
           if (p.bias_kind && col < p.bias_cols) {
             const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
             const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           }
-          float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
+          float4* o = reinterpret_cast<float4*>(outb + orow * p.ldo + col);
           if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
           *o = v;
         }
@@ -350,7 +375,7 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
     for (int i = 0; i < 4; ++i) {
       const int64_t m = m0 + wave * 32 + r * 16 + (lane >> 4) * 4 + i;
       if (m >= p.M) continue;
-      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t orow = proj_orow(p, m);
       const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
         float v = acc[r][nt][i];
         if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
         else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
-        float* o = p.out + orow * p.ldo + col;
+        float* o = outb + orow * p.ldo + col;
         if (p.accumulate) v += *o;
         *o = v;
       }
@@ -422,7 +447,7 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float4 v = *reinterpret_cast<const float4*>(A + rowc[r] * lda + h * 4);
+          const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rowc[r]) * lda + h * 4);
           dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
         }
     } else {                                                         // last k tile of a term: k past Kc reads as zero
@@ -432,7 +457,7 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
         for (int h = 0; h < 2; ++h) {
           const bool ok = k0 + kg * 8 + h * 4 < p.Kc;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok) v = *reinterpret_cast<const float4*>(A + rowc[r] * lda + h * 4);
+          if (ok) v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rowc[r]) * lda + h * 4);
           dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
         }
     }
@@ -536,7 +561,7 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
           const int col = n0 + seg;
           if (m >= p.M || col >= p.N) continue;
           float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
-          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          const int64_t orow = proj_orow(p, m);
           if (p.bias_kind && col < p.bias_cols) {
             const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
             const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
@@ -556,7 +581,7 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
     for (int i = 0; i < 4; ++i) {
       const int64_t m = m0 + wave * 32 + r * 16 + kg * 4 + i;
       if (m >= p.M) continue;
-      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t orow = proj_orow(p, m);
       const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -637,7 +662,7 @@ __global__ __launch_bounds__(1024 / RT) void project_resident_kernel(const ProjP
           const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
           const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
           const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
-          const float4 v = *reinterpret_cast<const float4*>(A + rr * lda + kc);
+          const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rr) * lda + kc);
           ra[i][0] = ok ? v.x : 0.f; ra[i][1] = ok ? v.y : 0.f; ra[i][2] = ok ? v.z : 0.f; ra[i][3] = ok ? v.w : 0.f;
         }
       } else {
@@ -646,7 +671,7 @@ __global__ __launch_bounds__(1024 / RT) void project_resident_kernel(const ProjP
           const bool ok = (m0 + i < p.M) && (k0 + lane < p.Kc);
           const int64_t rr = (m0 + i < p.M) ? m0 + i : p.M - 1;
           const int kc = (k0 + lane < p.Kc) ? k0 + lane : 0;
-          const float v = A[proj_row_off(p, rr, lda) + kc];
+          const float v = A[proj_row_off(p, proj_arow(p, term, rr), lda) + kc];
           ra[i][0] = ok ? v : 0.f;
         }
       }
@@ -727,7 +752,7 @@ __global__ __launch_bounds__(1024 / RT) void project_resident_kernel(const ProjP
         const float2 lo = *reinterpret_cast<const float2*>(&my[row * kResAS + seg]);
         const float2 hi = *reinterpret_cast<const float2*>(&my[row * kResAS + seg + 2]);
         float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
-        const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+        const int64_t orow = proj_orow(p, m);
         if (p.bias_kind && col < p.bias_cols) {
           const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
           const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
@@ -745,7 +770,7 @@ __global__ __launch_bounds__(1024 / RT) void project_resident_kernel(const ProjP
         for (int i = 0; i < 4; ++i) {
           const int64_t m = m0 + r * 16 + (lane >> 4) * 4 + i;
           if (m >= p.M) continue;
-          const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+          const int64_t orow = proj_orow(p, m);
           const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
@@ -813,7 +838,7 @@ __global__ __launch_bounds__(kBlock) void project_narrow_kernel(const ProjParams
     for (int j = 0; j < 4; ++j) {
       const int64_t m = mb0 + (it * 4 + j) * RP + r_in;
       if (m >= mend) continue;
-      const int64_t orow = (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+      const int64_t orow = proj_orow(p, m);
       float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       if (p.bias_kind && c4 < p.bias_cols) {
         const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;

@@ -52,6 +52,7 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "hop_xcd_remap") == 0) { g_hop_remap.store(value != 0); return TGCN_OK; }
+  if (key && strcmp(key, "hop_seg_remap") == 0) { g_hop_seg_remap.store(value != 0); return TGCN_OK; }
   if (key && strcmp(key, "hop_lds_pad") == 0) { if (value < 0 || value > 160 * 1024) TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: hop_lds_pad %d", value); g_hop_lds_pad.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
@@ -117,6 +118,7 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
     TGCN_FAIL(TGCN_ERR_INVALID, "hop: schedule built for %d lanes/row, C=%d (aligned16=%d) needs %d", S->lanes_per_row, C, al, g.lpr);
   if (S->nblk <= 0 || S->row_thresh <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: empty schedule");
   if (S->nseg < 0 || S->nlong < 0 || S->nhuge < 0 || S->nhuge > S->nlong || S->npartial < 0) TGCN_FAIL(TGCN_ERR_INVALID, "hop: bad schedule counts");
+  if (S->seg_mode != 0 && !(S->seg_mode == 1 && g.lpr < 64)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: seg_mode %d with %d lanes per row", S->seg_mode, g.lpr);
   if ((int64_t)nb * g.nchunks > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: nb*chunks=%lld > 65535", (long long)nb * g.nchunks);
   if (S->nseg > 0 && (!S->seg_row || !S->seg_e0 || !S->seg_e1 || !S->seg_slot)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null segment arrays");
   if (S->npartial > 0) {
@@ -138,6 +140,7 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
   p.alpha = alpha; p.beta = beta;
   p.nblk = S->nblk; p.nseg = S->nseg; p.nlong = S->nlong; p.nhuge = S->nhuge; p.row_thresh = S->row_thresh;
   p.C = C; p.nb = nb; p.nchunks = g.nchunks; p.cpad = g.cpad; p.remap = g_hop_remap.load();
+  p.seg_mode = S->seg_mode; p.seg_remap = g_hop_seg_remap.load();
   const int gpb = kBlock / g.lpr;
   const int seg_blocks = (S->nseg + gpb - 1) / gpb;
   const dim3 grid((unsigned)(S->nblk + seg_blocks), (unsigned)(nb * g.nchunks));
@@ -150,7 +153,8 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
 static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
-                        int32_t win_n, int32_t win_t, int32_t bias_cols = -1);
+                        int32_t win_n, int32_t win_t, int32_t bias_cols = -1, const int32_t* rowmap = nullptr, uint32_t mapped = 0,
+                        int32_t nbatch = 1, const int64_t* a_bs = nullptr, int64_t out_bs = 0);
 
 int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                           const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
@@ -171,14 +175,18 @@ int tgcn_cheb_project_windows_f32(void* stream, int64_t n_vertices, int32_t T, i
 static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
-                        int32_t win_n, int32_t win_t, int32_t bias_cols) {
+                        int32_t win_n, int32_t win_t, int32_t bias_cols, const int32_t* rowmap, uint32_t mapped,
+                        int32_t nbatch, const int64_t* a_bs, int64_t out_bs) {
+  if (nbatch < 1 || (nbatch > 1 && !a_bs)) TGCN_FAIL(TGCN_ERR_INVALID, "project: nbatch %d", nbatch);
   if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "project: bad argument");
   if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "project: bias_kind %d", bias_kind);
   if (interleave < 1 || n_vertices < 1) TGCN_FAIL(TGCN_ERR_INVALID, "project: interleave/n_vertices");
   if (interleave > 1 && M != interleave * n_vertices) TGCN_FAIL(TGCN_ERR_INVALID, "project: M != interleave*n_vertices");
+  if (rowmap && (interleave != 1 || win_n != 0)) TGCN_FAIL(TGCN_ERR_INVALID, "project: a row map excludes interleave / windows");
   ProjParams p;
   memset(&p, 0, sizeof(p));
+  p.rowmap = rowmap; p.mapped = rowmap ? mapped : 0u;
   bool vec4 = (Kc % 4 == 0) && win_n == 0;   // windows start at any float: scalar loads
   p.win_n = win_n; p.win_t = win_t;
   p.bias_cols = bias_cols < 0 ? N : bias_cols;   // bias rows have bias_cols floats
@@ -193,6 +201,31 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.bias_kind = bias_kind; p.accumulate = accumulate;
   p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
                    (p.bias_cols % 4 == 0);
+  p.nbatch = 1;
+  if (nbatch > 1) {
+    // samples sharing the tile rows: inside project_x3_kernel<NT, true> (bias tile kept in registers), a host loop otherwise
+    const int pv0 = g_proj_variant.load();
+    const bool x3 = pv0 == 3 || (pv0 == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
+    const bool narrow = (pv0 == 0 || pv0 == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && win_n == 0 && !rowmap && p.vec_epilogue && N <= 1024 && (M >= 4096 || pv0 == 5);
+    const bool v2 = (N + 15) / 16 > 4 && g_x3_form.load() == 2;      // project_x3v2_kernel takes the wide outputs
+    if (x3 && vec4 && !narrow && !v2) {
+      p.nbatch = nbatch; p.out_bs = out_bs;
+      for (int t = 0; t < nterms; ++t) {
+        p.a_bs[t] = a_bs[t];
+        if (a_bs[t] % 4 != 0) TGCN_FAIL(TGCN_ERR_INVALID, "project: sample stride of term %d not a multiple of 4 floats", t);
+      }
+      if (out_bs % 4 != 0) p.vec_epilogue = 0;
+    } else {
+      const float* ab[kMaxTerms];
+      for (int b = 0; b < nbatch; ++b) {
+        for (int t = 0; t < nterms; ++t) ab[t] = a[t] + (int64_t)b * a_bs[t];
+        const int rc = project_impl(stream, M, Kc, N, nterms, ab, lda, W, bias, bias_kind, n_vertices, interleave, accumulate,
+                                    out + (int64_t)b * out_bs, ldo, win_n, win_t, bias_cols, rowmap, mapped);
+        if (rc != TGCN_OK) return rc;
+      }
+      return TGCN_OK;
+    }
+  }
   const int nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
   hipStream_t st = (hipStream_t)stream;
   const int kc4 = (Kc + 3) / 4 * 4;
@@ -202,7 +235,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   // 1 exact-fp32 streaming, 2 exact-fp32 (W-resident with 16-row wave tiles when it fits), 3 bf16x3 always, 4 exact fp32 auto,
   // 5 vector-ALU kernel whenever it applies (auto uses it for sum(Kc) <= 16 and M >= 4096)
   const int pv = g_proj_variant.load();
-  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && win_n == 0 && p.vec_epilogue && N <= 1024 &&
+  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && win_n == 0 && !rowmap && p.vec_epilogue && N <= 1024 &&
       (M >= 4096 || pv == 5)) {
     // a few scalars per row: stream the output from the vector ALU (project_narrow_kernel)
     const int L = N / 4, RP = kBlock / L;
@@ -260,7 +293,9 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   if (vec4) hipLaunchKernelGGL((project_kernel<NTV, true>), grid, dim3(kBlock), 0, st, p);             \
   else hipLaunchKernelGGL((project_kernel<NTV, false>), grid, dim3(kBlock), 0, st, p);
   if (use_x3) {      // bf16x3 products on the bf16 matrix pipe
-    const dim3 grid3((unsigned)((M + 255) / 256), grid.y);
+    const int64_t gx3 = (M + 255) / 256 * p.nbatch;                   // sample-fastest: the nbatch workgroups of a tile are neighbours
+    if (gx3 > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: grid too large");
+    const dim3 grid3((unsigned)gx3, grid.y);
 #define TGCN_PROJ3(NTV)                                                                              \
   if (vec4 && NTV >= 6 && g_x3_form.load() == 2) hipLaunchKernelGGL((project_x3v2_kernel<NTV>), grid3, dim3(512), 0, st, p); /* wide outputs: compute-bound */ \
   else if (vec4) hipLaunchKernelGGL((project_x3_kernel<NTV, true>), grid3, dim3(512), 0, st, p);      \
@@ -624,6 +659,82 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
   if (side) {  // join: everything the side stream did is ordered before whatever the caller enqueues next
     for (int i = 0; i < 2 && i < pass; ++i)
       if (hipStreamWaitEvent(main_st, side->proj_done[i], 0) != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "forward: stream join failed");
+  }
+  return TGCN_OK;
+}
+
+// Workspace of the compacted forward: K-1 hop tensors of qc x (n_c + 1) x C floats (row n_c of every sample is the zero row that
+// entries pointing at an empty vertex gather from), then the long-row scratch of one hop.
+static void cfwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t n_c, int32_t C, int64_t qc, size_t* hop_bytes, size_t* off_part,
+                           size_t* total) {
+  *hop_bytes = align_up((size_t)qc * (size_t)(n_c + 1) * C * sizeof(float), 256) + 65 * 256;   // staggered like fwd_ws_layout
+  *off_part = (size_t)(K > 1 ? K - 1 : 0) * *hop_bytes;
+  *total = *off_part + align_up(tgcn_csr_hop_workspace_bytes(S, 1, C, 1), 256);      // hops run one time step per launch
+}
+
+size_t tgcn_cheb_forward_compact_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n_c, int32_t C, int64_t q_chunk) {
+  if (!S || K < 2 || q < 1 || n_c < 1 || C < 1) return 0;
+  const int64_t qc = (q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
+  size_t a, b, total;
+  cfwd_ws_layout(S, K, n_c, C, qc, &a, &b, &total);
+  return total;
+}
+
+int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const tgcn_csr* A_rest, const tgcn_csr_sched* S, int32_t K,
+                                  int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W, const float* bias,
+                                  int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows, int64_t n_empty,
+                                  int64_t q_chunk, void* workspace, size_t workspace_bytes) {
+  if (!A_first || !A_rest || !S || !x || !W || !out || !rows) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: null operand");
+  const int64_t n_c = A_first->n;
+  if (K < 2 || K > kMaxTerms || q < 1 || n < 1 || C < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: bad shape (K=%d)", K);
+  if (A_rest->n != n_c || A_rest->nnz != A_first->nnz || n_c < 1 || n_empty < 0 || n_c + n_empty != n || (n_empty > 0 && !empty_rows))
+    TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: %lld compact + %lld empty rows for n=%lld", (long long)n_c, (long long)n_empty, (long long)n);
+  if ((C % 4 == 0 && ((uintptr_t)x & 15)) || ((uintptr_t)workspace & 15)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: x/workspace must be 16-byte aligned");
+  const int64_t qc = (q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
+  if (qc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_compact: q_chunk %lld", (long long)qc);
+  size_t hop_bytes, off_part, total;
+  cfwd_ws_layout(S, K, n_c, C, qc, &hop_bytes, &off_part, &total);
+  if (!workspace || workspace_bytes < total) TGCN_FAIL(TGCN_ERR_WORKSPACE, "forward_compact: workspace %zu < %zu", workspace_bytes, total);
+  char* ws = (char*)workspace;
+  float* part = (float*)(ws + off_part);
+  const size_t part_bytes = total - off_part;
+  const int64_t bs_c = (n_c + 1) * (int64_t)C;            // sample stride of a compact hop tensor
+  auto hop_ptr = [&](int k) { return (float*)(ws + (size_t)(k - 1) * hop_bytes); };
+  hipStream_t st = (hipStream_t)stream;
+  // the zero row of the tensors that are gathered from (hops 1 .. K-2); no hop writes it, so once per call
+  for (int k = 1; k + 1 < K; ++k)
+    if (hipMemset2DAsync(hop_ptr(k) + n_c * (int64_t)C, (size_t)bs_c * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)qc, st) != hipSuccess)
+      TGCN_FAIL(TGCN_ERR_LAUNCH, "forward_compact: memset failed");
+  const float* terms[kMaxTerms];
+  int64_t ldas[kMaxTerms];
+  for (int k = 0; k < K; ++k) ldas[k] = C;
+  int rc;
+  int64_t a_bs[kMaxTerms];
+  a_bs[0] = n * (int64_t)C;
+  for (int k = 1; k < K; ++k) a_bs[k] = bs_c;
+  for (int64_t q0 = 0; q0 < q; q0 += qc) {
+    const int64_t qn = (q - q0 < qc) ? (q - q0) : qc;
+    const float* x0 = x + q0 * n * C;
+    // hops: one launch per hop and time step (a launch's gather working set stays one (n_c, C) slab)
+    for (int64_t b = 0; b < qn; ++b)
+      for (int k = 1; k < K; ++k) {
+        tgcn_dense X = {k == 1 ? const_cast<float*>(x0) + b * n * C : hop_ptr(k - 1) + b * bs_c, 0, C};
+        tgcn_dense Y = {hop_ptr(k) + b * bs_c, 0, C};
+        rc = tgcn_csr_hop_f32(stream, k == 1 ? A_first : A_rest, S, 1, C, &X, nullptr, 1.f, 0.f, &Y, nullptr, part, part_bytes);
+        if (rc != TGCN_OK) return rc;
+      }
+    // projection of the pass's qn time steps in one launch per row class: the per-vertex bias is read once per pass
+    terms[0] = x0;
+    for (int k = 1; k < K; ++k) terms[k] = hop_ptr(k);
+    float* o = out + q0 * n * N;
+    // vertices with stored entries: all K terms (x through the row map, hop tensors in compact rows)
+    rc = project_impl(stream, n_c, C, N, K, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, rows, 1u, (int32_t)qn, a_bs, n * (int64_t)N);
+    if (rc != TGCN_OK) return rc;
+    // the others: P_k = 0 for k >= 1, so out = x W_0 + bias
+    if (n_empty > 0) {
+      rc = project_impl(stream, n_empty, C, N, 1, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, empty_rows, 1u, (int32_t)qn, a_bs, n * (int64_t)N);
+      if (rc != TGCN_OK) return rc;
+    }
   }
   return TGCN_OK;
 }

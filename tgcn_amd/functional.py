@@ -33,7 +33,9 @@ def _aligned16(C_row, *tensors):
 # ----------------------------------------------------------------------------------------- single ops
 def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=None, z2=None, gamma=0.0):
     """One hop:  S = L x;  y = alpha*S + beta*z (+ gamma*z2);  optionally also S.  x: (nb, op.n_cols, C); y, z, z2, S:
-    (nb, op.n, C); any of them may be a strided view as long as the last dim is contiguous.  Returns y (and S when want_p)."""
+    (nb, op.n, C); any of them may be a strided view as long as the last dim is contiguous.  Returns y (and S when want_p).
+    Low-level: rows are in the OPERAND's labels -- for a GraphOperand.reordered() operand the caller relabels (x[:, op.perm] in,
+    y[:, op.inv_perm] out), as cheb_layer / cheb_stack / cheb_time_windows / cheb_relu_pool do."""
     _lib.require_device(x, z, z2)
     L = _lib.lib()
     assert x.dim() == 3 and x.dtype == torch.float32 and x.shape[1] == op.n_cols, (x.shape, op.n_cols)
@@ -171,6 +173,11 @@ def cheb_time_windows(op, series, weight_khg, bias, bias_kind, mode=MODE_POWER):
     once on the T columns of each recording -- in the backward too (ChebWindowsFn), so the windows it replaces can be
     trained through."""
     _lib.require_device(series, weight_khg, bias)
+    if op.perm is not None:        # reordered operand: its hops work in their own labels (differentiable index ops, as in cheb_layer)
+        series = series.index_select(1, op.perm)
+        if bias is not None and bias_kind == BIAS_VERTEX_CHANNEL:
+            bias = bias.reshape(op.n, -1).index_select(0, op.perm)
+        return ChebWindowsFn.apply(series, weight_khg, bias, op, mode, bias_kind).index_select(1, op.inv_perm)
     return ChebWindowsFn.apply(series, weight_khg, bias, op, mode, bias_kind)
 
 
@@ -230,17 +237,43 @@ def cheb_forward_raw(op, x3, Wt, bias, bias_kind, mode, K, layout=None, q_chunk=
     return out
 
 
-def cheb_stack(op, x3, K, mode):
+def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
+    """Mode-0 forward on an operand with structurally empty rows (graph.CompactPlan) through tgcn_cheb_forward_compact_f32:
+    hop tensors only for the vertices that have entries.  x3: (q, n, C) contiguous; Wt: (K*C, N) folded."""
+    _lib.require_device(x3, Wt, bias)
+    L = _lib.lib()
+    q, n, Crow = x3.shape
+    N = Wt.shape[1]
+    assert x3.is_contiguous() and Wt.is_contiguous() and Wt.shape[0] == K * Crow and n == plan.n and K >= 2
+    if x3.data_ptr() % 16:
+        x3 = x3.clone()
+    if q_chunk is None:
+        q_chunk = COMPACT_Q_CHUNK
+    if q_chunk is None:
+        # time steps per pass: the hops still run one time step per launch; a pass's projection reads a per-vertex bias once
+        # for all its time steps, so take up to 4 while the K-1 compact hop tensors stay within a quarter of the free memory
+        q_chunk = 1
+        if bias_kind == BIAS_VERTEX_CHANNEL and q > 1:
+            free = torch.cuda.mem_get_info(x3.device)[0]
+            per_q = (K - 1) * (plan.n_c + 1) * Crow * 4
+            q_chunk = int(max(1, min(q, 4, (free // 4) // max(per_q, 1))))
+    sched = plan.schedule_for(Crow, Crow % 4 == 0)
+    ws_bytes = L.tgcn_cheb_forward_compact_workspace_bytes(C.byref(sched.struct), K, q, plan.n_c, Crow, q_chunk)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
+    out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
+    _lib.check(L.tgcn_cheb_forward_compact_f32(_lib.stream_ptr(), C.byref(plan.first.struct), C.byref(plan.rest.struct),
+                                               C.byref(sched.struct), K, q, n, Crow, N, _lib.ptr(x3), _lib.ptr(Wt), _lib.ptr(bias),
+                                               bias_kind, _lib.ptr(out), _lib.ptr(plan.rows), _lib.ptr(plan.empty), plan.n_empty,
+                                               q_chunk, _lib.ptr(ws), ws.numel()))
+    return out
+
+
+def cheb_stack(op, x3, K, mode, _operand_labels=False):
     """The (K, q, n, C) stack `_chebyshev` / `_time_chebyshev` return (gcn.py:52-79,126-154,208-237), or the
     true-recurrence stack for mode 1.  Materialising path: every hop writes its slice of the stack."""
     _lib.require_device(x3)
-    if op.perm is not None:
-        perm, inv = op.perm, op.inv_perm
-        op.perm = None
-        try:
-            return cheb_stack(op, x3.index_select(1, perm), K, mode).index_select(2, inv)
-        finally:
-            op.perm = perm
+    if op.perm is not None and not _operand_labels:       # reordered operand: relabel on the way in and out (the shared operand is never touched)
+        return cheb_stack(op, x3.index_select(1, op.perm), K, mode, _operand_labels=True).index_select(2, op.inv_perm)
     q, n, Crow = x3.shape
     st = torch.empty((K, q, n, Crow), dtype=torch.float32, device=x3.device)
     st[0].copy_(x3)
@@ -353,6 +386,8 @@ def cheb_forward_pf(op, x3, Wt_kcn, bias, bias_kind, mode):
 
 
 PROJECT_FIRST = True   # developer switch
+COMPACT = True         # developer switch: compact hop tensors for operands with many empty rows (graph.CompactPlan)
+COMPACT_Q_CHUNK = None # developer switch: time steps per pass of the compacted forward (None: chosen by cheb_forward_compact)
 
 
 def use_project_first(q, n, C_row, N):
@@ -369,6 +404,9 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     Wt = fold_weight(fold, W) if fold is not None else W
     if use_project_first(x3.shape[0], x3.shape[1], Crow, N):
         return cheb_forward_pf(op, x3, Wt, b, bias_kind, mode)
+    plan = op.compact_plan() if (COMPACT and mode == MODE_POWER and 2 <= K <= 32 and choose_layout(x3.shape[0], x3.shape[1], Crow) == 0) else None
+    if plan is not None:            # many structurally empty rows: compact hop tensors
+        return cheb_forward_compact(plan, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, K)
     return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
 
 
@@ -412,7 +450,7 @@ class ChebLayerFn(torch.autograd.Function):
     small-graph path, by tgcn_fold_weight_f32 otherwise; backward applies the transposed fold to the weight gradient."""
 
     @staticmethod
-    def forward(ctx, x3, W, bias, op, mode, bias_kind):
+    def forward(ctx, x3, W, bias, op, mode, bias_kind, grad_mode=True):
         K, Crow, N = W.shape
         x3 = x3.contiguous()
         W = W.contiguous()
@@ -420,7 +458,9 @@ class ChebLayerFn(torch.autograd.Function):
         fold = power_fold_matrix(K, W.device) if (mode == MODE_POWER and K > 2) else None
         ctx.basis = None
         general = not small_path_tile(op, Crow, mode) and not use_project_first(x3.shape[0], x3.shape[1], Crow, N)
-        if general and K > 1 and ctx.needs_input_grad[1] and K * x3.numel() * 4 <= KEEP_BASIS_BYTES:
+        # grad_mode: whether the CALLER records gradients (inside forward() grad mode is always off, and needs_input_grad only
+        # mirrors requires_grad): an inference call under torch.no_grad() keeps nothing for a backward that never comes
+        if general and K > 1 and grad_mode and ctx.needs_input_grad[1] and K * x3.numel() * 4 <= KEEP_BASIS_BYTES:
             Wt = fold_weight(fold, W) if fold is not None else W
             out, rows, nq = forward_keeping_basis(op, x3, Wt, b, bias_kind, mode)
             ctx.basis = (rows, nq)
@@ -437,7 +477,7 @@ class ChebLayerFn(torch.autograd.Function):
         gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad,
                                     basis=ctx.basis)
         ctx.basis = None
-        return gx, gW, gb, None, None, None
+        return gx, gW, gb, None, None, None, None
 
 
 def _monomial_stack(op, x3, K):
@@ -475,7 +515,7 @@ def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode):
     """Differentiable fused layer; weight_kcn: (K, C, N) in the reference basis."""
     x3, weight_kcn = _pad_rows(op, x3, weight_kcn, mode)
     x3, bias = _to_operand_labels(op, x3, bias, bias_kind)
-    out = ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind)
+    out = ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind, torch.is_grad_enabled())
     return out if op.perm is None else out.index_select(1, op.inv_perm)
 
 

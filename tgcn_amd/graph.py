@@ -13,11 +13,15 @@ from . import _lib
 
 ROW_THRESH = 32         # rows with more stored entries are processed as column-ordered segments
 SEG_LEN = 32            # stored entries per segment (measured on cfg5: 32 beats 16/64/128/256, tools/hop_bench.py)
+SEG_MODE = 0            # 0: one lane group per segment (shipped); 1: one WAVE per segment of SEG_LEN * (64 / lanes) entries, pieces folded in
+                        # the wave -- 4.7x fewer partial rows but the column-ordered sweep loses its locality: cfg5 hop 3.82 -> 4.44 ms
 SEG_KEY = "first"       # column of the segment used as its place in the processing order
 HUGE_SLOTS = 64         # long rows with more segments than this get a whole workgroup in the fix-up
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
 DENSE_MAX_N = 256       # operands up to this size that store >= 1/4 of their entries also keep a dense copy
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
+COMPACT_MIN_ROWS = 1 << 16     # operands at least this large ...
+COMPACT_MIN_EMPTY = 0.125      # ... with at least this share of structurally empty rows keep compact hop tensors (CompactPlan)
 BLOCK_ROWS_MAX = None   # cost of a row block at most this many entry-equivalents per lane group (None: 64 for rows up to 64 floats, else 256)
 
 
@@ -34,9 +38,12 @@ def _check_range(row, col, n, ncol):
 class Schedule:
     """Work schedule for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
 
-    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None):
+    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None, seg_mode=None):
         row_thresh = ROW_THRESH if row_thresh is None else row_thresh
         seg_len = max(SEG_LEN if seg_len is None else seg_len, 1)
+        seg_mode = (SEG_MODE if seg_mode is None else seg_mode) if lanes_per_row < 64 else 0
+        if seg_mode == 1:
+            seg_len *= 64 // lanes_per_row          # a wave's lane groups share the segment
         dev = rowptr.device
         gpb = 256 // lanes_per_row
         deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
@@ -102,10 +109,43 @@ class Schedule:
         self.lanes_per_row = lanes_per_row
         self.row_thresh = row_thresh
         self.seg_len = seg_len
-        self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, 0,
+        self.seg_mode = seg_mode
+        self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, seg_mode,
                                        self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
                                        self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
                                        self.long_slot.data_ptr())
+
+
+class CompactPlan:
+    """Operand with structurally empty rows (R-MAT: 5.27 M of 10 M vertices; the isolated fake vertices the reference's
+    coarsening pads with, gcn/coarsening.py:167-217) prepared for tgcn_cheb_forward_compact_f32: hop tensors exist only for
+    the n_c vertices that have stored entries.  `first` = the n_c non-empty rows with columns in the caller's labels (hop 1
+    gathers from x), `rest` = the same rows and entry order with columns in compact ids -- an entry whose column is an
+    empty vertex points at the zero row n_c -- for hops 2..K-1; `rows` / `empty` = caller's label of every compact / empty
+    row, ascending.  Both operands share one schedule (same row pointers, same entry order)."""
+
+    def __init__(self, op, keep):
+        dev = op.device
+        self.n = op.n
+        rows = keep.nonzero().flatten()
+        self.n_c = int(rows.numel())
+        self.rows = _as_i32(rows)
+        self.empty = _as_i32((~keep).nonzero().flatten())
+        self.n_empty = int(self.empty.numel())
+        rowptr_c = torch.cat([op.rowptr[:-1][keep], op.rowptr[-1:]]).contiguous()
+        cid = torch.full((op.n,), self.n_c, dtype=torch.int32, device=dev)
+        cid[rows] = torch.arange(self.n_c, dtype=torch.int32, device=dev)
+        edges_c = op.edges.clone()
+        if op.nnz:
+            edges_c[:, 0] = cid[op.edges[:, 0].long()]
+        del cid
+        self.first = GraphOperand._from_packed(self.n_c, rowptr_c, op.edges, op.nnz, n_cols=op.n)
+        self.rest = GraphOperand._from_packed(self.n_c, rowptr_c, edges_c, op.nnz, n_cols=self.n_c + 1)
+        self.first._sched = self.rest._sched       # one schedule: built from `rest`, valid for both
+        self.first._lock = self.rest._lock
+
+    def schedule_for(self, C_row, aligned16=True):
+        return self.rest.schedule_for(C_row, aligned16)
 
 
 class GraphOperand:
@@ -113,31 +153,57 @@ class GraphOperand:
 
     def __init__(self, n, rowptr, col, val, n_cols=None):
         assert rowptr.dtype == torch.int32 and col.dtype == torch.int32 and val.dtype == torch.float32
+        nnz = int(col.numel())
+        edges = torch.empty((max(nnz, 1), 2), dtype=torch.int32, device=rowptr.device)
+        if nnz:
+            edges[:, 0] = col
+            edges[:, 1] = val.view(torch.int32)
+        self._init_packed(n, rowptr, edges, nnz, n_cols)
+
+    @staticmethod
+    def _from_packed(n, rowptr, edges, nnz, n_cols=None):
+        """Operand over an existing packed entry array (shared, not copied)."""
+        op = GraphOperand.__new__(GraphOperand)
+        op._init_packed(n, rowptr, edges, nnz, n_cols)
+        return op
+
+    def _init_packed(self, n, rowptr, edges, nnz, n_cols):
+        assert rowptr.dtype == torch.int32 and edges.dtype == torch.int32 and edges.shape[1] == 2
         self.n = int(n)
         self.n_cols = int(n if n_cols is None else n_cols)   # > n for a vertex shard: owned rows x (owned + halo) columns
-        self.nnz = int(col.numel())
+        self.nnz = int(nnz)
         if self.nnz >= 2 ** 31 - 1 or self.n >= 2 ** 31 - 1:
             raise _lib.TgcnError("graph operand outside the int32 index range (n=%d nnz=%d)" % (self.n, self.nnz))
         self.device = rowptr.device
         self.rowptr = rowptr.contiguous()
-        edges = torch.empty((max(self.nnz, 1), 2), dtype=torch.int32, device=self.device)
-        if self.nnz:
-            edges[:, 0] = col
-            edges[:, 1] = val.view(torch.int32)
         self.edges = edges
         # small dense operands (the 148-parcel DTI graph of load/res): a dense copy for the matrix-pipe kernels
         self.dense = None
         if self.n_cols == self.n and 16 <= self.n <= DENSE_MAX_N and self.nnz * 4 >= self.n * self.n:
             counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
             rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), counts)
-            self.dense = torch.sparse_coo_tensor(torch.stack([rows, col.to(torch.int64)]), val, (self.n, self.n)).coalesce().to_dense().contiguous()
+            col, val = edges[: self.nnz, 0].to(torch.int64), edges[: self.nnz, 1].contiguous().view(torch.float32)
+            self.dense = torch.sparse_coo_tensor(torch.stack([rows, col]), val, (self.n, self.n)).coalesce().to_dense().contiguous()
         self.struct = _lib.CsrStruct(self.n, self.nnz, self.rowptr.data_ptr(), self.edges.data_ptr(),
                                      self.dense.data_ptr() if self.dense is not None else None)
         self._sched = {}
         self._lock = threading.RLock()
         self._transpose = None
+        self._compact = False     # CompactPlan, None when the operand does not qualify, False until asked
         self.perm = None          # reordered(): internal row i holds the caller's vertex perm[i]
         self.inv_perm = None
+
+    def compact_plan(self):
+        """CompactPlan when enough rows are structurally empty for compact hop tensors to pay, else None (built once)."""
+        with self._lock:
+            if self._compact is False:
+                self._compact = None
+                if self.n == self.n_cols and self.n >= COMPACT_MIN_ROWS and self.nnz > 0:
+                    keep = self.rowptr[1:] > self.rowptr[:-1]
+                    n_c = int(keep.sum().item())
+                    if 0 < n_c and (self.n - n_c) >= COMPACT_MIN_EMPTY * self.n:
+                        self._compact = CompactPlan(self, keep)
+            return self._compact
 
     def __deepcopy__(self, memo):
         """An operand is immutable once built (device arrays + ctypes structs that point into them): copies of a module share it."""
@@ -288,7 +354,10 @@ class GraphOperand:
 
     def to(self, device):
         row, col, val = self.coo()
-        return GraphOperand.from_coo(self.n, row, col, val, device, n_cols=self.n_cols)
+        op = GraphOperand.from_coo(self.n, row, col, val, device, n_cols=self.n_cols)
+        if self.perm is not None:           # a reordered operand stays one on the other device
+            op.perm, op.inv_perm = self.perm.to(device), self.inv_perm.to(device)
+        return op
 
     def schedule(self, lanes_per_row):
         with self._lock:                  # replicas of one module may share an operand (nn.DataParallel threads)

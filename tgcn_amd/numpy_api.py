@@ -25,8 +25,9 @@ def _chebyshev_f64(L, X, K, device):
     """float64 operand: the recursion in fp64 on the device (tgcn_csr_hop_f64), as the reference's L.dtype arithmetic"""
     import ctypes as C
     from . import _lib
+    # the caller's matrix is never touched (tocsr() of a CSR returns the object itself), and entries keep their stored order,
+    # which is the order the reference's L.dot sums them in (gcn/graph.py:256-265)
     Lc = L.tocsr() if hasattr(L, "tocsr") else __import__("scipy.sparse").sparse.csr_matrix(np.asarray(L))
-    Lc.sort_indices()
     n = Lc.shape[0]
     rp = torch.as_tensor(Lc.indptr.astype(np.int32), device=device)
     ci = torch.as_tensor(Lc.indices.astype(np.int32), device=device)

@@ -30,6 +30,10 @@ def main():
     ap.add_argument("--fold-cols", type=int, default=None, help="replace every column c by c %% H spread over the table: the same row structure with all gathers inside an H-row hot set (upper bound of any locality scheme)")
     ap.add_argument("--block-cost", type=int, default=None, help="graph.BLOCK_ROWS_MAX: entry-equivalents per lane group and row block (default 256)")
     ap.add_argument("--remap", default="1", help="comma list of hop_xcd_remap values, each crossed with the others")
+    ap.add_argument("--seg-modes", default="1", help="comma list of tgcn_csr_sched.seg_mode values (0 lane-group segments, 1 wave segments)")
+    ap.add_argument("--seg-remaps", default="0", help="comma list of hop_seg_remap values")
+    ap.add_argument("--compact", action="store_true", help="time the hop on the compacted operand (graph.CompactPlan.rest: only rows with entries)")
+    ap.add_argument("--drop-core", type=int, default=None, help="remove the entries whose row AND column are among the H vertices of largest degree (what a hub-core kernel would take over)")
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     args = ap.parse_args()
     from tools import synth
@@ -50,6 +54,13 @@ def main():
         _, row, col, val = synth.rmat(args.n, args.nnz, labeling=args.labeling, device=dev)
     if args.fold_cols:
         col = (col % args.fold_cols) * (args.n // args.fold_cols)
+    if args.drop_core:
+        deg = torch.bincount(row, minlength=args.n)
+        hub = torch.zeros(args.n, dtype=torch.bool, device=dev)
+        hub[torch.argsort(deg, descending=True)[: args.drop_core]] = True
+        keep = ~(hub[row] & hub[col])
+        print("hub core %d x %d holds %d of %d entries" % (args.drop_core, args.drop_core, int((~keep).sum()), row.numel()), flush=True)
+        row, col, val = row[keep], col[keep], val[keep]
     if args.only != "all":
         deg = torch.bincount(row, minlength=args.n)
         thr = args.row_thresh or graph.ROW_THRESH
@@ -58,12 +69,21 @@ def main():
         print("kept %d entries (%s rows)" % (row.numel(), args.only), flush=True)
     op = graph.GraphOperand.from_coo(args.n, row, col, val, dev)
     del row, col, val
+    if args.compact:
+        plan = op.compact_plan()
+        print("compact: %d rows with entries, %d empty" % (plan.n_c, plan.n_empty), flush=True)
+        op = plan.rest
+    lanes = _lib.lib().tgcn_hop_lanes_per_row(args.C // args.split, 1)
+    scheds = {m: graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, seg_mode=m) for m in sorted(set(int(m) for m in args.seg_modes.split(",")))}
+    for m, sm in scheds.items():
+        print("seg_mode %d: blocks=%d segments=%d long rows=%d huge=%d partial slots=%d seg_len=%d" % (m, sm.nblk, sm.nseg, sm.nlong, sm.nhuge, sm.npartial, sm.seg_len), flush=True)
     s = op.schedule_for(args.C // args.split)
     print("n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d)" % (op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len), flush=True)
-    x = torch.randn(1, op.n, args.C, device=dev)
-    y = torch.empty_like(x)
+    x = torch.randn(1, op.n_cols, args.C, device=dev)
+    y = torch.empty(1, op.n, args.C, device=dev)
     ref = None
-    variants = [(int(v), int(pd), int(rm)) for v in args.variants.split(",") for pd in args.lds_pads.split(",") for rm in args.remap.split(",")]
+    variants = [(int(v), int(pd), int(rm), int(sm), int(sr)) for v in args.variants.split(",") for pd in args.lds_pads.split(",") for rm in args.remap.split(",")
+                for sm in args.seg_modes.split(",") for sr in args.seg_remaps.split(",")]
     times = {v: [] for v in variants}
     fix = {v: [] for v in variants}
     L = _lib.lib()
@@ -72,6 +92,8 @@ def main():
             _lib.check(L.tgcn_set_tuning(b"hop_variant", v[0]))
             _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", v[1] * 1024))
             _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", v[2]))
+            _lib.check(L.tgcn_set_tuning(b"hop_seg_remap", v[4]))
+            op._sched[lanes] = scheds[v[3]]
             _lib.profile_start(16)
             cs = args.C // args.split
             for sp in range(args.split):
@@ -81,13 +103,14 @@ def main():
                 if ref is None:
                     ref = y.clone()
                 else:
-                    assert torch.equal(ref, y), "variant %s changed the result" % (v,)
+                    assert torch.allclose(ref, y, rtol=1e-4, atol=1e-5), "variant %s changed the result" % (v,)
                 continue
             times[v].append(sum(ms for k, ms in prof if k == 0))
             fix[v].append(sum(ms for k, ms in prof if k == 1))
     _lib.check(L.tgcn_set_tuning(b"hop_variant", 0))
     _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", 0))
     _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", 1))
+    _lib.check(L.tgcn_set_tuning(b"hop_seg_remap", 0))
     alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph in ('rmat', 'banded') else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
