@@ -187,10 +187,57 @@ def cpu_baseline(op, spec, layer, x, samples=(0,)):
                      sample="samples %s of the %d of the same workload, full K=%d forward, oracle/cheb_ref.c OpenMP, %.1f s" % (samples, spec["q"], K, dt))
 
 
-def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards):
+# ---- rehearsal compute (tests only): `--rehearsal-cpu` runs this file's N > 1 control flow (rendezvous, time sharding, extras,
+# watchdog, the one JSON line) with the gloo backend on the CPU, the HIP calls replaced by scipy / numpy stand-ins that are
+# injected through the hooks tgcn_amd/dist.py has for exactly this.  Nothing measured in this mode is a result (`data` says so);
+# tests/test_bench_rehearsal.py drives it at world 2 under `pytest -m "not gpu"`.
+class _CpuOperand:
+    def __init__(self, n_rows, n_cols, row, col, val, device):
+        import scipy.sparse as sp
+        self.n, self.n_cols, self.nnz = n_rows, n_cols, int(row.numel())
+        self.L = sp.coo_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n_rows, n_cols)).tocsr()
+
+
+def _cpu_hop(op, x, z, alpha, beta, out):
+    y = np.stack([op.L.dot(x[b].numpy()) for b in range(x.shape[0])]).astype(np.float32)
+    y = alpha * y + (beta * z.numpy() if z is not None else 0)
+    return out.copy_(torch.from_numpy(y.astype(np.float32)))
+
+
+def _cpu_project(terms, W, bias, bias_kind, n_vertices):
+    acc = sum(t.numpy() @ W[k].numpy() for k, t in enumerate(terms))
+    if bias_kind:
+        acc = acc + bias.numpy()
+    return torch.from_numpy(acc.astype(np.float32))
+
+
+def _cpu_pack(src, idx, out):
+    return out.copy_(src.index_select(0, idx))
+
+
+class _CpuLayer:
+    """reference_power layer on the CPU (tgcn/nn/gcn.py:66-78 + :39): stands in for the HIP module in rehearsals"""
+    def __init__(self, op, spec):
+        self.L = op.to_scipy()
+        self.K = spec["K"]
+        g = torch.Generator().manual_seed(1)
+        self.W = (torch.rand(self.K, spec["H"] * spec["f"], spec["g"], generator=g) - 0.5).numpy()
+        self.bias = None
+
+    def __call__(self, x):
+        q, n = x.shape[0], x.shape[1]
+        xs = x.reshape(q, n, -1).numpy()
+        Xt, P = [xs], xs
+        for k in range(1, self.K):
+            P = np.stack([self.L.dot(P[b]) for b in range(q)])
+            Xt.append(P if k == 1 else 2 * P - Xt[k - 2])
+        return torch.from_numpy(sum(Xt[k] @ self.W[k] for k in range(self.K)).astype(np.float32))
+
+
+def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, rehearsal=False):
     """The vertex-sharded layer of SURVEY.md 8(e) on the same workload: every rank holds the seeded graph, owns an nnz-balanced
     row range (inside its group of `vertex_shards` ranks for mode "hybrid"; the groups split the q_total time steps, no
-    communication between them) and its slice of x / bias.  -> (callable, VertexShardedCheb, groups, time steps of this group)"""
+    communication between them) and its slice of x / bias.  -> (callable(overlap), VertexShardedCheb, groups, time steps of this group)"""
     import tgcn_amd
     from tgcn_amd import functional as _F
     from tgcn_amd.dist import VertexShardedCheb, hybrid_groups, shard_time_steps
@@ -201,56 +248,82 @@ def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards):
     sl = shard_time_steps(q_total, gi, ngroups)
     q = sl.stop - sl.start
     row, col, val = op.coo()
-    sh = VertexShardedCheb(op.n, row, col, val, group=group, device=device, exchange="auto")
+    hooks = dict(make_operand=_CpuOperand, hop_fn=_cpu_hop, project_fn=_cpu_project, pack_fn=_cpu_pack) if rehearsal else {}
+    sh = VertexShardedCheb(op.n, row, col, val, group=group, device=device, exchange="auto", **hooks)
     del row, col, val
     K = spec["K"]
     torch.manual_seed(1)
     C_in = spec["H"] * spec["f"]                       # TGCNCheb_H: the H time steps of a window are the row
     Wraw = torch.empty(K, C_in, spec["g"], device=device)
     tgcn_amd.uniform(C_in * K, Wraw)
-    Wf = _F.fold_weight(_F.power_fold_matrix(K, device), Wraw) if K > 2 else Wraw
+    Wf = Wraw if (K <= 2 or rehearsal) else _F.fold_weight(_F.power_fold_matrix(K, device), Wraw)
     bias_local = torch.zeros(sh.owned, spec["g"], device=device)
     g = torch.Generator(device=device).manual_seed(rank)
     x_local = torch.randn((max(q, 1), sh.owned, C_in), device=device, generator=g)[:q]
-    return (lambda _x=None: sh.forward(x_local, Wf, bias_local, 2, 0)), sh, ngroups, q
+    return (lambda overlap=True: sh.forward(x_local, Wf, bias_local, 2, 0, overlap=overlap)), sh, ngroups, q
 
 
-def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress=None):
-    """Vertex-sharded and hybrid runs of the same workload (2 timed forwards each).  They must never cost the headline: every
-    failure becomes an entry with an `error`, and if they overrun --extras-budget the caller's line is printed without them
-    (the watchdog thread of every rank ends its process)."""
-    out = []
+def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress=None, out=None):
+    """Vertex-sharded and hybrid runs of the same workload (2 timed forwards each), each in two forms: "plain" (one blocking
+    exchange per hop, then the hop: the form with the fewest ways to go wrong on a first contact with RCCL) and "overlapped"
+    (in-place receives, interior rows and other time steps under the exchange).  They must never cost the headline: every failure
+    becomes an entry with an `error`, entries are appended to `out` as they finish, and if the runs overrun --extras-budget the
+    caller's watchdog prints the headline with the entries finished so far and ends every rank with a non-zero code.
+    Every entry carries what each rank exchanges per hop (rows, bytes per channel and peer) and its per-phase times, so a slow or
+    wrong run can be diagnosed from the one line."""
+    out = [] if out is None else out
     K, H = spec["K"], spec["H"]
+    rehearsal = getattr(args, "rehearsal_cpu", False)
     modes = [("vertex", world)] + ([("hybrid", 2)] if world >= 4 and world % 2 == 0 else [])
     for mode, vs in modes:
-        entry = dict(shard=mode, vertex_shards=vs)
-        if progress is not None:
-            progress["mode"] = mode
         try:
-            fwd, sh, ngroups, qg = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs)
-            steps = 2
-            with torch.no_grad():
-                fwd()
-                sync_all()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    fwd()
-                sync_all()
-                dt = time.perf_counter() - t0
-            tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-            entry.update(value=round(op.nnz * (K - 1) * q_total * H * steps / dt / 1e9, 3), unit="G edge\u00b7timesteps/s", ms_per_step=round(dt / steps * 1e3, 3),
-                         steps=steps, scaling="strong", exchange=sh.exchange, groups=ngroups, time_steps_per_group=qg, owned_rows_rank0=sh.owned,
-                         interior_rows_rank0=sh.n_int, halo_rows_rank0=sh.halo)
-            del fwd, sh
-            torch.cuda.empty_cache()
+            if progress is not None:
+                progress["mode"] = "%s: building shards" % mode
+            fwd, sh, ngroups, qg = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs, rehearsal)
         except Exception as e:      # noqa: BLE001 -- reported, never fatal
             import traceback
             traceback.print_exc()
             sys.stderr.flush()
-            entry["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
-        out.append(entry)
+            out.append(dict(shard=mode, vertex_shards=vs, error="%s: %s" % (type(e).__name__, str(e)[:300])))
+            continue
+        for form, overlap in (("plain", False), ("overlapped", True)):
+            entry = dict(shard=mode, vertex_shards=vs, form=form)
+            if progress is not None:
+                progress["mode"] = "%s / %s" % (mode, form)
+            try:
+                steps = 2
+                sh.collect_stats = False
+                with torch.no_grad():
+                    fwd(overlap)
+                    sync_all()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        fwd(overlap)
+                    sync_all()
+                    dt = time.perf_counter() - t0
+                    sh.collect_stats = True                # one more forward with the phase log (device events add their own syncs)
+                    fwd(overlap)
+                    sync_all()
+                    sh.collect_stats = False
+                tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+                mine = dict(sh.describe(), phases_ms=sh.stats)
+                per_rank = [None] * world
+                dist.all_gather_object(per_rank, mine)
+                C_in = spec["H"] * spec["f"]
+                entry.update(value=round(op.nnz * (K - 1) * q_total * H * steps / dt / 1e9, 3), unit="G edge·timesteps/s", ms_per_step=round(dt / steps * 1e3, 3),
+                             steps=steps, scaling="strong", exchange=sh.exchange, groups=ngroups, time_steps_per_group=qg,
+                             message_bytes_per_hop_and_time_step_rank0=mine["bytes_per_channel_in"] * C_in, ranks=per_rank)
+            except Exception as e:      # noqa: BLE001 -- reported, never fatal
+                import traceback
+                traceback.print_exc()
+                sys.stderr.flush()
+                entry["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+            out.append(entry)
+        del fwd, sh
+        if device.type == "cuda":
+            torch.cuda.empty_cache()
     return out
 
 
@@ -273,16 +346,22 @@ def main():
     ap.add_argument("--compact-q-chunk", type=int, default=None, help="developer: time steps per pass of the compacted forward")
     ap.add_argument("--no-compact", action="store_true", help="developer: hop tensors for all vertices even when many rows are empty")
     ap.add_argument("--no-extras", action="store_true", help="N > 1, time sharding: skip the vertex-sharded / hybrid runs reported in `other_shardings`")
+    ap.add_argument("--rehearsal-cpu", action="store_true", help="tests only: run the N > 1 control flow on the CPU with the gloo backend and scipy stand-ins for the HIP calls; nothing measured in this mode is a result")
     ap.add_argument("--extras-budget", type=float, default=150.0, help="seconds after which the extra runs are abandoned and the headline line is printed without them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    local = local % torch.cuda.device_count()      # rehearsals may put several ranks on one card
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    rehearsal = args.rehearsal_cpu
+    if rehearsal:
+        args.backend, args.no_cpu = "gloo", True
+        device = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        local = local % torch.cuda.device_count()      # rehearsals may put several ranks on one card
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
@@ -310,7 +389,7 @@ def main():
     vertex_mode = world > 1 and args.shard in ("vertex", "hybrid")
     ngroups = 1
     if vertex_mode:
-        fwd, sh, ngroups, q = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards)
+        fwd, sh, ngroups, q = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards, rehearsal)
         spec["q"] = q
 
         class _Sharded:
@@ -318,15 +397,20 @@ def main():
             def __call__(self, _x):
                 return fwd()
         layer, x = _Sharded(), None
+    elif rehearsal:
+        layer = _CpuLayer(op, spec)
+        x = make_input(op, spec, device, seed=rank)
     else:
         layer = make_layer(op, spec, device)
         x = make_input(op, spec, device, seed=rank)
 
     def sync_all():
-        torch.cuda.synchronize()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if device.type == "cuda":
+                torch.cuda.synchronize()
 
     with torch.no_grad():
         # set-up, not a step: one forward so that the caching allocator owns the output / workspace blocks (a cold
@@ -337,14 +421,15 @@ def main():
             out = None
             out = layer(x)
         sync_all()
-        _lib.profile_start(65536)
+        if not rehearsal:
+            _lib.profile_start(65536)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = None
             out = layer(x)
         sync_all()
         dt = time.perf_counter() - t0
-        prof = _lib.profile_stop(65536)
+        prof = [] if rehearsal else _lib.profile_stop(65536)
     if world > 1:
         tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -441,7 +526,7 @@ def main():
     if rank == 0:
         line = dict(metric=baseline_metric(), value=round(value, 3), unit="G edge\u00b7timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if (vertex_mode or strong_time or world == 1) else "weak", vs_baseline=None,
-                    dtype="f32", data="synthetic",
+                    dtype="f32", data="rehearsal on the CPU with scipy stand-ins: control flow only, NOT a measurement" if rehearsal else "synthetic",
                     config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
                                 sharding=(("%d group(s) x %d vertex shards, %s exchange per hop inside a group" % (ngroups, sh.world, sh.exchange)) if ngroups > 1 else ("vertex rows across ranks, %s exchange per hop" % sh.exchange)) if vertex_mode else (("the %d time steps of the workload split over %d ranks (%d on rank 0), CSR replicated, no collective" % (q_total, world, q) if strong_time else "%d time steps per rank, CSR replicated, no collective" % q) if world > 1 else "single GPU"),
                                 nnz=op.nnz, n=op.n,
@@ -455,6 +540,7 @@ def main():
         import threading
         printed = threading.Lock()         # exactly one JSON line, whoever gets there first
         progress = dict(mode=None)
+        extras = []                        # entries finished so far: the watchdog prints them with the headline
 
         def bail():
             # a stalled exchange (or a GPU hang) in the extras: the headline is still valid, so print it -- marked -- and end every
@@ -463,13 +549,13 @@ def main():
                 return
             if rank == 0:
                 line["extras_abandoned"] = True
-                line["other_shardings"] = [dict(error="abandoned after %.0f s (--extras-budget)" % args.extras_budget, last_started=progress["mode"])]
+                line["other_shardings"] = list(extras) + [dict(error="abandoned after %.0f s (--extras-budget)" % args.extras_budget, last_started=progress["mode"])]
                 print(json.dumps(line), flush=True)
             os._exit(3)
         dog = threading.Timer(args.extras_budget, bail)
         dog.daemon = True
         dog.start()
-        extras = run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress)
+        run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress, extras)
         dog.cancel()
         if not printed.acquire(blocking=False):      # the watchdog fired while the extras were returning: it prints and exits
             time.sleep(3600)

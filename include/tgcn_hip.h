@@ -302,6 +302,18 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
                                      const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
                                      int32_t relu, int32_t pool, float* out, uint8_t* pool_idx);
 int tgcn_relu_pool_f32(void* stream, const float* x, float* out, uint8_t* idx, int64_t q, int64_t n, int32_t f, int32_t p);
+
+/* The layer of tgcn_cheb_forward_f32 followed by relu + max over `pool` consecutive vertices for graphs that do NOT fit in LDS:
+ * out (q, n/pool, N), pool_idx (nullable) as above.  On the (q, n, C) layout with up to 32 terms and N <= 64 output columns
+ * the epilogue runs inside the projection kernel (bias, relu and the max over 2 / 4 / 8 / 16 rows of the finished tile), so the
+ * (q, n, N) layer output is never written; other shapes run the layer into workspace scratch followed by tgcn_relu_pool_f32
+ * (the workspace query accounts for it).  pool = 1: relu only. */
+size_t tgcn_cheb_forward_pool_workspace_bytes(const tgcn_csr_sched* sched, int32_t K, int64_t q, int64_t n, int32_t C, int32_t N,
+                                              int32_t layout, int64_t q_chunk, int32_t pool);
+int tgcn_cheb_forward_pool_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t mode, int32_t K, int64_t q,
+                               int64_t n, int32_t C, int32_t N, const float* x, const float* W, const float* bias, int32_t bias_kind,
+                               int32_t pool, float* out, uint8_t* pool_idx, int32_t layout, int64_t q_chunk, void* workspace,
+                               size_t workspace_bytes);
 int tgcn_relu_pool_bwd_f32(void* stream, const float* grad_z, const float* z, const uint8_t* idx, float* grad_y, int64_t q,
                            int64_t n, int32_t f, int32_t p);
 

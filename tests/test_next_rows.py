@@ -189,3 +189,62 @@ def test_reordered_operand_in_forward_series_and_to(kind, gpu_device):
     assert rel_err(sb.grad.cpu().numpy(), sa.grad.cpu().numpy()) <= 2e-5
     assert rel_err(lb.weight.grad.cpu().numpy(), la.weight.grad.cpu().numpy()) <= 2e-5
     assert rel_err(lb.bias.grad.cpu().numpy(), la.bias.grad.cpu().numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("case", ["mesh59k_gcn32x64_pool4", "mesh90k_tgcn64x64_pool2", "grid_exact_pool4", "mesh_layout1_fallback"])
+def test_relu_pool_in_the_projection_epilogue(case, gpu_device):
+    """SURVEY 8f-2 for graphs that do not fit in LDS: bias + relu + max over 2 / 4 consecutive vertices inside the projection's
+    epilogue (tgcn_cheb_forward_pool_f32) -- against the ORACLE's pool(relu(forward)) on the 59,536-vertex mesh and at 90 k
+    vertices, bitwise against layer + separate relu/pool pass (values and arg-max bytes), gradients against the unfused
+    modules.  The last case is a shape the epilogue does not cover (vertex-major rows): same entry point, scratch + extra pass."""
+    import tgcn_amd
+    from tgcn_amd import functional as F, _lib
+    from tools import synth
+    rng = np.random.default_rng(3)
+    if case == "mesh59k_gcn32x64_pool4":          # second layer of the reference's HCP model on the cortical-mesh size
+        n, row, col, val = synth.sheet_mesh(244)
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 32, 64, 5)), 2, 32, 4, True
+        ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
+    elif case == "mesh90k_tgcn64x64_pool2":
+        n, row, col, val = synth.sheet_mesh(300)
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.TGCNCheb(o, 64, 64, 4)), 1, 64, 2, True
+        ref = lambda L, x, W, b: O.tgcn_cheb_forward(L, x, W, b)
+    elif case == "grid_exact_pool4":              # small problem: the exact-fp32 W-resident kernel's epilogue
+        n, row, col, val = synth.sheet_mesh(40)
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 32, 16, 3)), 2, 32, 4, True
+        ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
+    else:
+        n, row, col, val = synth.sheet_mesh(60)
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 8, 16, 3)), 3, 8, 4, False
+        ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
+    assert n % pool == 0
+    op = tgcn_amd.GraphOperand.from_coo(n, row, col, val)
+    torch.manual_seed(4)
+    layer = mk(op).cuda()
+    K = layer.filter_order
+    N = layer.out_channels
+    assert F.small_path_tile(op, C, F.MODE_POWER) == 0
+    assert F.pool_epilogue_is_fused(op, q, C, N, K, pool) == fused
+    x = rng.standard_normal((q, n, C)).astype(np.float32)
+    L = op.to_scipy()
+    want = O.gcn_pool(np.maximum(ref(L, x, layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()), 0), pool)
+    x1 = _dev(x).requires_grad_(True)
+    z1 = tgcn_amd.cheb_relu_pool(layer, x1, pool=pool)
+    assert rel_err(z1.detach().cpu().numpy(), want) <= TOL
+    # the same kernels without the fusion: layer, then the relu + pool pass -- identical values and arg-max bytes
+    with torch.no_grad():
+        y = layer(_dev(x))
+        z2 = torch.empty_like(z1)
+        i2 = torch.empty(z1.shape, dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().tgcn_relu_pool_f32(_lib.stream_ptr(), _lib.ptr(y), _lib.ptr(z2), _lib.ptr(i2), q, n, N, pool))
+    assert torch.equal(z1.detach(), z2)
+    # gradients against the unfused modules
+    gz = torch.randn_like(z1)
+    z1.backward(gz)
+    g1 = [x1.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone()]
+    layer.zero_grad()
+    x2 = _dev(x).requires_grad_(True)
+    yy = torch.relu(layer(x2))
+    (tgcn_amd.gcn_pool_4(yy) if pool == 4 else tgcn_amd.gcn_pool(yy)).backward(gz)
+    for a, b in zip(g1, [x2.grad, layer.weight.grad, layer.bias.grad]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5

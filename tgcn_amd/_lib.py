@@ -77,6 +77,11 @@ SIGNATURES = {
     "tgcn_cheb_forward_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
                                         C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P,
                                         C.c_int32, C.c_int64, _P, C.c_size_t]),
+    "tgcn_cheb_forward_pool_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                                            C.c_int32, C.c_int64, C.c_int32]),
+    "tgcn_cheb_forward_pool_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                             C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int64, _P,
+                                             C.c_size_t]),
     "tgcn_cheb_forward_compact_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64]),
     "tgcn_cheb_forward_compact_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32,
                                                 C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P,

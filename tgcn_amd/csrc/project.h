@@ -30,7 +30,51 @@ struct ProjParams {
   int32_t nbatch;
   int64_t a_bs[kMaxTerms];
   int64_t out_bs;
+  // Fused epilogue of the callers' x = gcn_pool_4(F.relu(layer(x))) (tgcn/nn/gcn.py:246-255, examples/pytorch_based/
+  // pytorch_hcp_tgcn.py:134-141): pool > 1 stores max over `pool` consecutive tile rows (vertices of one sample) of relu(result +
+  // bias) at out row m / pool, so the (q, n, N) layer output is never written; pool_idx (nullable) gets the arg-max offset
+  // for the backward.  Kernels with the vector epilogue only (project_x3_kernel NT <= 4, project_resident_kernel); no row map,
+  // no interleave, no accumulate; pool divides 16.
+  int32_t pool;
+  uint8_t* pool_idx;
 };
+
+// relu + max over p.pool consecutive rows of a wave's finished tile rows held in LDS scratch (`rows` rows of `stride` floats, NW
+// columns from n0), first tile row = vertex row `mbase` (a multiple of p.pool): what relu_pool_kernel computes from the stored
+// layer output (first maximum wins, NaN propagates), without storing it.
+__device__ __forceinline__ void pooled_store(const ProjParams& p, const float* my, int stride, int rows, int64_t mbase, int n0, int NW,
+                                             int lane) {
+  const int segs = NW >> 2, groups = rows / p.pool;
+  for (int idx = lane; idx < groups * segs; idx += 64) {
+    const int pr = idx / segs, seg = (idx % segs) * 4;
+    const int64_t m = mbase + (int64_t)pr * p.pool;
+    const int col = n0 + seg;
+    if (m >= p.M || col >= p.N) continue;          // M is a multiple of pool: a group is inside or outside as a whole
+    float best[4];
+    int bi[4] = {0, 0, 0, 0};
+    for (int j = 0; j < p.pool; ++j) {
+      const float* src = my + (pr * p.pool + j) * stride + seg;
+      float v[4] = {src[0], src[1], src[2], src[3]};
+      if (p.bias_kind && col < p.bias_cols) {
+        const int64_t vert = (m + j) % p.n_vertices;
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (j == 0 || v[c] > best[c] || (v[c] != v[c] && best[c] == best[c])) { best[c] = v[c]; bi[c] = j; }
+    }
+    float4 o;
+    o.x = best[0] > 0.f ? best[0] : (best[0] != best[0] ? best[0] : 0.f);
+    o.y = best[1] > 0.f ? best[1] : (best[1] != best[1] ? best[1] : 0.f);
+    o.z = best[2] > 0.f ? best[2] : (best[2] != best[2] ? best[2] : 0.f);
+    o.w = best[3] > 0.f ? best[3] : (best[3] != best[3] ? best[3] : 0.f);
+    const int64_t orow = m / p.pool;
+    *reinterpret_cast<float4*>(p.out + orow * p.ldo + col) = o;
+    if (p.pool_idx)
+      *reinterpret_cast<uint32_t*>(p.pool_idx + orow * p.ldo + col) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  }
+}
 
 // row of term `term` that tile row m reads
 __device__ __forceinline__ int64_t proj_arow(const ProjParams& p, int term, int64_t m) {
@@ -347,6 +391,10 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * ES + nt * 16 + (lane & 15)] = acc[r][nt][i];
+        if (p.pool > 1) {            // relu + max over consecutive vertices instead of the plain store (wave-uniform branch)
+          pooled_store(p, my, ES, 16, m0 + wave * 32 + r * 16, n0, NW, lane);
+          continue;
+        }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
           const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
@@ -743,6 +791,10 @@ __global__ __launch_bounds__(1024 / RT) void project_resident_kernel(const ProjP
           for (int i = 0; i < 4; ++i) my[(r * 16 + (lane >> 4) * 4 + i) * kResAS + nt * 16 + (lane & 15)] = acc[r][nt][i];
       constexpr int SEGS = NW / 4;                        // float4 per row
       constexpr int ITER = (kResRows * SEGS) / 64;
+      if (p.pool > 1) {
+        pooled_store(p, my, kResAS, kResRows, m0, n0, NW, lane);
+        continue;                                         // next tile of this wave
+      }
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;

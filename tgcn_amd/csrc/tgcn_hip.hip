@@ -154,7 +154,21 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
                         int32_t win_n, int32_t win_t, int32_t bias_cols = -1, const int32_t* rowmap = nullptr, uint32_t mapped = 0,
-                        int32_t nbatch = 1, const int64_t* a_bs = nullptr, int64_t out_bs = 0);
+                        int32_t nbatch = 1, const int64_t* a_bs = nullptr, int64_t out_bs = 0, int32_t pool = 0, uint8_t* pool_idx = nullptr);
+
+// Whether project_impl's dispatch (below) lands on a kernel with the fused relu + pool epilogue for this shape: the W-resident
+// exact kernel or project_x3_kernel with at most 4 column tiles, both through their vector epilogue.  Keep in step with the
+// dispatch in project_impl.
+static bool project_pool_fusable(int64_t M, int32_t Kc, int32_t N, int32_t nterms, int32_t pool) {
+  if (pool < 2 || 16 % pool != 0 || M % pool != 0 || N % 4 != 0 || nterms > kMaxTerms) return false;
+  const int pv = g_proj_variant.load();
+  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && N <= 1024 && (M >= 4096 || pv == 5)) return false;   // narrow kernel
+  const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
+  const int nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
+  const size_t wbytes = (size_t)nterms * ((Kc + 3) / 4 * 4) * nt * 16 * sizeof(float);
+  if (wbytes <= (size_t)kResMaxWBytes && pv != 1 && !use_x3) return true;                                                  // resident
+  return use_x3 && (N + 15) / 16 <= 4;                                                                                      // x3, NT <= 4
+}
 
 int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                           const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
@@ -176,7 +190,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
                         int32_t win_n, int32_t win_t, int32_t bias_cols, const int32_t* rowmap, uint32_t mapped,
-                        int32_t nbatch, const int64_t* a_bs, int64_t out_bs) {
+                        int32_t nbatch, const int64_t* a_bs, int64_t out_bs, int32_t pool, uint8_t* pool_idx) {
   if (nbatch < 1 || (nbatch > 1 && !a_bs)) TGCN_FAIL(TGCN_ERR_INVALID, "project: nbatch %d", nbatch);
   if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "project: bad argument");
   if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
@@ -201,6 +215,11 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.bias_kind = bias_kind; p.accumulate = accumulate;
   p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
                    (p.bias_cols % 4 == 0);
+  if (pool > 1) {     // fused relu + max-pool epilogue: only where the dispatch below takes a kernel that has it
+    if (rowmap || interleave != 1 || accumulate || win_n != 0 || nbatch != 1 || !p.vec_epilogue || !project_pool_fusable(M, Kc, N, nterms, pool))
+      TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: no fused pool epilogue for this shape (M=%lld Kc=%d N=%d terms=%d pool=%d)", (long long)M, Kc, N, nterms, pool);
+    p.pool = pool; p.pool_idx = pool_idx;
+  }
   p.nbatch = 1;
   if (nbatch > 1) {
     // samples sharing the tile rows: inside project_x3_kernel<NT, true> (bias tile kept in registers), a host loop otherwise
@@ -580,10 +599,56 @@ size_t tgcn_cheb_forward_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int
   return total;
 }
 
+static int forward_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t mode, int32_t K,
+                        int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
+                        const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
+                        void* workspace, size_t workspace_bytes, int32_t pool, uint8_t* pool_idx);
+
 int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t mode, int32_t K,
                           int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
                           const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
                           void* workspace, size_t workspace_bytes) {
+  return forward_impl(stream, A, S, mode, K, q, n, C, N, x, W, bias, bias_kind, out, layout, q_chunk, workspace, workspace_bytes, 0, nullptr);
+}
+
+// shapes whose layer forward can end in the fused relu + pool epilogue: (sample, vertex) row order, one projection call per pass
+static bool forward_pool_fusable(int32_t K, int64_t q, int64_t n, int32_t C, int32_t N, int32_t layout, int64_t q_chunk, int32_t pool) {
+  if (layout != 0 || K > kMaxTerms || n % pool != 0) return false;
+  const int64_t qc = (q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
+  // every pass must take the same kind of kernel: check the full and the last (shorter) pass
+  const int64_t last = q % qc ? q % qc : qc;
+  return project_pool_fusable(qc * n, C, N, K, pool) && project_pool_fusable(last * n, C, N, K, pool);
+}
+
+size_t tgcn_cheb_forward_pool_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t C, int32_t N,
+                                              int32_t layout, int64_t q_chunk, int32_t pool) {
+  const size_t base = tgcn_cheb_forward_workspace_bytes(S, K, q, n, C, layout, q_chunk);
+  if (base == 0 || pool < 1) return 0;
+  return align_up(base, 256) + (forward_pool_fusable(K, q, n, C, N, layout, q_chunk, pool) ? 0 : align_up((size_t)q * n * N * sizeof(float), 256));
+}
+
+int tgcn_cheb_forward_pool_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t mode, int32_t K, int64_t q,
+                               int64_t n, int32_t C, int32_t N, const float* x, const float* W, const float* bias, int32_t bias_kind,
+                               int32_t pool, float* out, uint8_t* pool_idx, int32_t layout, int64_t q_chunk, void* workspace,
+                               size_t workspace_bytes) {
+  if (pool < 1 || pool > 255 || n % pool != 0 || !out) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pool: pool=%d n=%lld", pool, (long long)n);
+  const size_t base = align_up(tgcn_cheb_forward_workspace_bytes(S, K, q, n, C, layout, q_chunk), 256);
+  const bool aligned = (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) && (!pool_idx || ((uintptr_t)pool_idx & 3) == 0);
+  if (pool > 1 && aligned && forward_pool_fusable(K, q, n, C, N, layout, q_chunk, pool))       // the (q, n, N) layer output is never written
+    return forward_impl(stream, A, S, mode, K, q, n, C, N, x, W, bias, bias_kind, out, layout, q_chunk, workspace, workspace_bytes, pool, pool_idx);
+  // other shapes: the layer into scratch, then the relu + pool pass
+  const size_t need = base + align_up((size_t)q * n * N * sizeof(float), 256);
+  if (!workspace || workspace_bytes < need) TGCN_FAIL(TGCN_ERR_WORKSPACE, "forward_pool: workspace %zu < %zu", workspace_bytes, need);
+  float* y = (float*)((char*)workspace + base);
+  int rc = forward_impl(stream, A, S, mode, K, q, n, C, N, x, W, bias, bias_kind, y, layout, q_chunk, workspace, base, 0, nullptr);
+  if (rc != TGCN_OK) return rc;
+  return tgcn_relu_pool_f32(stream, y, out, pool_idx, q, n, N, pool);
+}
+
+static int forward_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t mode, int32_t K,
+                        int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
+                        const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
+                        void* workspace, size_t workspace_bytes, int32_t pool, uint8_t* pool_idx) {
   if (!A || !S || !x || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "forward: null operand");
   if (K < 1 || q < 1 || n < 1 || C < 1 || N < 1 || n != A->n) TGCN_FAIL(TGCN_ERR_INVALID, "forward: bad shape (n=%lld, L is %lld)", (long long)n, (long long)A->n);
   if (mode != 0 && mode != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward: mode %d", mode);
@@ -645,13 +710,15 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
     }
     // projection, in chunks of <= 32 terms
     const int64_t M = (layout == 1) ? n * q : qn * n;
-    float* o0 = (layout == 1) ? out : out + q0 * n * N;
+    const int pl = pool > 1 ? pool : 1;              // pooled epilogue (layout 0, K <= 32 terms): output rows shrink by the pool
+    float* o0 = (layout == 1) ? out : out + q0 * (n / pl) * N;
     for (int k0 = 0; k0 < K; k0 += kMaxTerms) {
       const int nt = (K - k0 < kMaxTerms) ? K - k0 : kMaxTerms;
       for (int t = 0; t < nt; ++t) { terms[t] = hop_ptr(k0 + t); ldas[t] = C; }
       const bool last = (k0 + nt >= K);
-      rc = tgcn_cheb_project_f32(proj_stream, M, C, N, nt, terms, ldas, W + (size_t)k0 * C * N, last ? bias : nullptr,
-                                 last ? bias_kind : 0, n, layout == 1 ? q : 1, k0 > 0 ? 1 : 0, o0, N);
+      rc = project_impl(proj_stream, M, C, N, nt, terms, ldas, W + (size_t)k0 * C * N, last ? bias : nullptr,
+                        last ? bias_kind : 0, n, layout == 1 ? q : 1, k0 > 0 ? 1 : 0, o0, N, 0, 0, -1, nullptr, 0, 1, nullptr, 0,
+                        pool > 1 ? pool : 0, pool_idx ? pool_idx + q0 * (n / pl) * N : nullptr);
       if (rc != TGCN_OK) return rc;
     }
     if (side && hipEventRecord(side->proj_done[set], side->st) != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "forward: event record failed");

@@ -98,6 +98,8 @@ class VertexShardedCheb:
         self.device = torch.device(device) if device is not None else row.device
         self.hop_fn, self.project_fn, self.pack_fn = hop_fn, project_fn, pack_fn
         self._bufs = {}
+        self.collect_stats = False      # True: forward() times its phases on this rank (device events / wall clock) into self.stats
+        self.stats = None
         row, col, val = row.to(self.device), col.to(self.device), val.to(self.device)
         self.n = n
         self.bounds = balanced_row_bounds(row, n, self.world)
@@ -171,8 +173,47 @@ class VertexShardedCheb:
         """buffers of the overlapped path live as long as the object (no allocation per hop)"""
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape):
-            t = self._bufs[name] = torch.empty(shape, dtype=torch.float32, device=self.device)
+            # zeroed once: padding rows of the all-gather blocks ([owned:n_max]) are never written, and they go on the wire
+            t = self._bufs[name] = torch.zeros(shape, dtype=torch.float32, device=self.device)
         return t
+
+    # ------------------------------------------------------------------ diagnostics
+    def describe(self):
+        """what this rank exchanges per hop and time step: enough to tell a slow link from a wrong partition in one record"""
+        C4 = 4
+        d = dict(rank=self.rank, exchange=self.exchange, owned_rows=self.owned, interior_rows=self.n_int, halo_rows=self.halo,
+                 ext_rows=self.n_ext, nnz=self.op.nnz if hasattr(self.op, "nnz") else None)
+        if self.exchange == "halo":
+            d["recv_rows_per_peer"] = list(self.recv_counts)
+            d["send_rows_per_peer"] = [int(i.numel()) for i in self.send_idx]
+            d["bytes_per_channel_in"] = C4 * sum(self.recv_counts)
+        else:
+            d["allgather_block_rows"] = self.n_max
+            d["bytes_per_channel_in"] = C4 * self.n_max * (self.world - 1)
+        return d
+
+    def _mark(self, marks, name):
+        """one time stamp of the phase log: a device event on the current stream (GPU) or the wall clock (CPU rehearsals)"""
+        if marks is None:
+            return
+        if self.device.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+        else:
+            import time
+            marks.append((name, time.perf_counter()))
+
+    def _close_stats(self, marks):
+        if marks is None:
+            return
+        tot = {}
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            ms = a.elapsed_time(b) if self.device.type == "cuda" else (b - a) * 1e3
+            tot[name] = tot.get(name, 0.0) + ms
+        self.stats = {k: round(v, 3) for k, v in tot.items()}
 
     def _start_exchange(self, slot, k, src_ext):
         """Start fetching the remote rows of hop tensor `src_ext` ((1, n_ext, C), owned part valid) into its own halo region;
@@ -210,6 +251,8 @@ class VertexShardedCheb:
         bias_l = bias_local
         if bias_kind == 2 and bias_local is not None and not allg:
             bias_l = bias_local.index_select(0, self.local_perm)
+        marks = [] if self.collect_stats else None
+        self._mark(marks, "start")
         for t0 in range(0, q, depth):
             steps = range(t0, min(q, t0 + depth))
             # hop tensors of a time step: K buffers of (1, n_ext, C) [halo] or (n_max, C) + one gathered copy [all-gather]
@@ -232,22 +275,28 @@ class VertexShardedCheb:
                         works[s] = [dist.all_gather_into_tensor(ext[s].view(self.world * self.n_max, C), mine[s][k - 1], group=self.group, async_op=True)]
                     else:
                         works[s] = self._start_exchange(s - t0, k, exts[s][k - 1])
+                self._mark(marks, "pack_and_post_ms")
                 if not allg and ni:
                     for s in steps:                                   # 2. interior rows: no remote column, no wait
                         z = own(s, k - 2)[:, : ni] if (mode != 0 and k >= 2) else None
                         self.hop_fn(self.op_int, exts[s][k - 1], z, 2.0 if z is not None else 1.0, -1.0 if z is not None else 0.0, own(s, k)[:, : ni])
+                    self._mark(marks, "interior_hops_ms")
                 for s in steps:                                       # 3. boundary rows as their halo arrives
                     for w in works[s]:
                         w.wait()
+                    self._mark(marks, "exchange_wait_ms")
                     src = ext[s] if allg else exts[s][k - 1]
                     opb = self.op if allg else self.op_bnd
                     if opb is not None:
                         z = own(s, k - 2)[:, ni:] if (mode != 0 and k >= 2) else None
                         self.hop_fn(opb, src, z, 2.0 if z is not None else 1.0, -1.0 if z is not None else 0.0, own(s, k)[:, ni:])
+                    self._mark(marks, "boundary_hops_ms")
             for s in steps:
                 o = self.project_fn([own(s, k).reshape(owned, C) for k in range(K)], W, bias_l, bias_kind, owned)
                 o = o.reshape(owned, N)
                 out[s] = o if allg else o.index_select(0, self.local_inv)
+            self._mark(marks, "projection_ms")
+        self._close_stats(marks)
         return out
 
     # ------------------------------------------------------------------ layer, one exchange after the other
@@ -262,6 +311,8 @@ class VertexShardedCheb:
         bias_l = bias_local
         if halo and bias_kind == 2 and bias_local is not None:
             bias_l = bias_local.index_select(0, self.local_perm)
+        marks = [] if self.collect_stats else None
+        self._mark(marks, "start")
         for s in range(q):
             xs = x_local[s].index_select(0, self.local_perm) if halo else x_local[s]
             terms = [xs.unsqueeze(0)]
@@ -275,10 +326,14 @@ class VertexShardedCheb:
                     mine = torch.zeros((self.n_max, C), dtype=torch.float32, device=xs.device)
                     mine[: owned] = terms[k - 1][0]
                     dist.all_gather_into_tensor(ext.view(self.world * self.n_max, C), mine, group=self.group)
+                self._mark(marks, "exchange_ms")
                 y = torch.empty((1, owned, C), dtype=torch.float32, device=xs.device)
                 z = terms[k - 2] if (mode != 0 and k >= 2) else None
                 self.hop_fn(self.op_all, ext, z, 2.0 if z is not None else 1.0, -1.0 if z is not None else 0.0, y)
                 terms.append(y)
+                self._mark(marks, "hops_ms")
             o = self.project_fn([t.reshape(owned, C) for t in terms], W, bias_l, bias_kind, owned).reshape(owned, N)
             out[s] = o.index_select(0, self.local_inv) if halo else o
+            self._mark(marks, "projection_ms")
+        self._close_stats(marks)
         return out

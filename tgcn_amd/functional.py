@@ -268,6 +268,41 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
     return out
 
 
+def cheb_forward_pool(op, x3, Wt, bias, bias_kind, mode, K, pool, z, idx, layout=None, q_chunk=None):
+    """relu + max-pool fused layer on the hops-then-projection path (tgcn_cheb_forward_pool_f32) into z (q, n/pool, N) and the
+    arg-max bytes idx.  x3: (q, n, C) contiguous; Wt: (K*C, N) in the working basis."""
+    _lib.require_device(x3, Wt, bias, z, idx)
+    L = _lib.lib()
+    q, n, Crow = x3.shape
+    N = Wt.shape[1]
+    assert x3.is_contiguous() and Wt.is_contiguous() and Wt.shape[0] == K * Crow and n == op.n and z.is_contiguous() and idx.is_contiguous()
+    if x3.data_ptr() % 16:
+        x3 = x3.clone()
+    if layout is None:
+        layout = choose_layout(q, n, Crow)
+    if q_chunk is None:
+        q_chunk = choose_q_chunk(q, n, Crow)
+    hop_C = q * Crow if layout == 1 else Crow
+    sched = op.schedule_for(hop_C, hop_C % 4 == 0)
+    ws_bytes = L.tgcn_cheb_forward_pool_workspace_bytes(C.byref(sched.struct), K, q, n, Crow, N, layout, q_chunk, pool)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
+    _lib.check(L.tgcn_cheb_forward_pool_f32(_lib.stream_ptr(), C.byref(op.struct), C.byref(sched.struct), mode, K, q, n, Crow, N,
+                                            _lib.ptr(x3), _lib.ptr(Wt), _lib.ptr(bias), bias_kind, pool, _lib.ptr(z), _lib.ptr(idx),
+                                            layout, q_chunk, _lib.ptr(ws), ws.numel()))
+    return z
+
+
+def pool_epilogue_is_fused(op, q, Crow, N, K, pool, layout=None, q_chunk=None):
+    """True when cheb_forward_pool runs relu + pool inside the projection kernel for this shape (no scratch for the layer output)."""
+    L = _lib.lib()
+    layout = choose_layout(q, op.n, Crow) if layout is None else layout
+    q_chunk = choose_q_chunk(q, op.n, Crow) if q_chunk is None else q_chunk
+    hop_C = q * Crow if layout == 1 else Crow
+    sched = op.schedule_for(hop_C, hop_C % 4 == 0)
+    base = L.tgcn_cheb_forward_workspace_bytes(C.byref(sched.struct), K, q, op.n, Crow, layout, q_chunk)
+    return L.tgcn_cheb_forward_pool_workspace_bytes(C.byref(sched.struct), K, q, op.n, Crow, N, layout, q_chunk, pool) < base + q * op.n * N * 4
+
+
 def cheb_stack(op, x3, K, mode, _operand_labels=False):
     """The (K, q, n, C) stack `_chebyshev` / `_time_chebyshev` return (gcn.py:52-79,126-154,208-237), or the
     true-recurrence stack for mode 1.  Materialising path: every hop writes its slice of the stack."""
@@ -600,6 +635,12 @@ class ChebReluPoolFn(torch.autograd.Function):
             _lib.check(L.tgcn_cheb_forward_small_pool_f32(_lib.stream_ptr(), C.byref(op.struct), mode, K, q, Crow, N, _lib.ptr(x3),
                                                           _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
                                                           _lib.ptr(z), _lib.ptr(idx)))
+        elif (not small_path_tile(op, Crow, mode) and not use_project_first(q, n, Crow, N)
+              and not (COMPACT and mode == MODE_POWER and 2 <= K <= 32 and choose_layout(q, n, Crow) == 0 and op.compact_plan() is not None)):
+            # hops-then-projection path: bias + relu + max over `pool` vertices inside the projection's epilogue where the shape allows
+            # (tgcn_cheb_forward_pool_f32: the (q, n, N) layer output is then never written), one extra pass over scratch otherwise
+            Wt = fold_weight(fold, W) if fold is not None else W
+            cheb_forward_pool(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K, pool, z, idx)
         else:
             y = layer_forward(op, x3, W, fold, b, bias_kind, mode)
             _lib.check(L.tgcn_relu_pool_f32(_lib.stream_ptr(), _lib.ptr(y), _lib.ptr(z), _lib.ptr(idx), q, n, N, pool))
@@ -623,10 +664,37 @@ class ChebReluPoolFn(torch.autograd.Function):
 def cheb_relu_pool(op, x3, weight_kcn, bias, bias_kind, mode, pool):
     """Differentiable relu + max-pool fused layer; weight in the reference basis."""
     x3, weight_kcn = _pad_rows(op, x3, weight_kcn, mode)
-    if op.perm is not None:     # pooling groups consecutive vertices of the CALLER's labelling: relabel back before the pool
-        y = torch.relu(cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode))
-        return PoolMaxFn.apply(y, pool)
+    if op.perm is not None:
+        # pooling groups consecutive vertices of the CALLER's labelling, which are scattered rows of a reordered operand: the
+        # epilogue cannot be fused there -- the layer's output is relabelled back first, then one relu + pool pass (HIP)
+        return ReluPoolFn.apply(cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode), pool)
     return ChebReluPoolFn.apply(x3, weight_kcn, bias, op, mode, bias_kind, pool)
+
+
+class ReluPoolFn(torch.autograd.Function):
+    """z = max over `pool` consecutive vertices of relu(y) as its own pass (tgcn_relu_pool_f32 / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, y, pool):
+        _lib.require_device(y)
+        y = y.float().contiguous()
+        q, n, N = y.shape
+        assert n % pool == 0, "pooling needs n divisible by the pool size"
+        z = torch.empty((q, n // pool, N), dtype=torch.float32, device=y.device)
+        idx = torch.empty((q, n // pool, N), dtype=torch.uint8, device=y.device)
+        _lib.check(_lib.lib().tgcn_relu_pool_f32(_lib.stream_ptr(), _lib.ptr(y), _lib.ptr(z), _lib.ptr(idx), q, n, N, pool))
+        ctx.save_for_backward(z, idx)
+        ctx.shape, ctx.pool = (q, n, N), pool
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        z, idx = ctx.saved_tensors
+        q, n, N = ctx.shape
+        gy = torch.empty((q, n, N), dtype=torch.float32, device=gz.device)
+        _lib.check(_lib.lib().tgcn_relu_pool_bwd_f32(_lib.stream_ptr(), _lib.ptr(gz.contiguous()), _lib.ptr(z), _lib.ptr(idx), _lib.ptr(gy),
+                                                     q, n, N, ctx.pool))
+        return gy, None
 
 
 def pack_rows(src, idx, out):
