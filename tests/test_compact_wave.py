@@ -202,3 +202,28 @@ def test_offsets_beyond_2_31_elements(gpu_device):
     lhs = F.cheb_forward_compact(plan, 0.5 * a + b, W, None, 0, K)
     rhs = 0.5 * F.cheb_forward_compact(plan, a.clone(), W, None, 0, K) + F.cheb_forward_compact(plan, b.clone(), W, None, 0, K)
     assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= TOL
+
+
+@pytest.mark.parametrize("M", [70000, 90000, 300])
+def test_wide_bf16x3_projection_tail_tiles(M, gpu_device):
+    """project_x3v2_kernel hands the rows of a thinly filled last round out as 128-row tiles (cfg4: 352 tiles = 256 + 96 on 256
+    CUs): same arithmetic per row, so bitwise the result of 256-row tiles throughout, and the fp64 product within tolerance."""
+    from tgcn_amd import functional as F, _lib
+    rng = np.random.default_rng(M)
+    Kc, N, T = 72, 160, 2
+    terms = [rng.standard_normal((M, Kc)).astype(np.float32) for _ in range(T)]
+    W = (rng.standard_normal((T, Kc, N)) / np.sqrt(T * Kc)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = sum(t.astype(np.float64) @ w.astype(np.float64) for t, w in zip(terms, W)) + bias
+    L = _lib.lib()
+    _lib.check(L.tgcn_set_tuning(b"project_variant", 3))
+    try:
+        outs = []
+        for tail in (1, 0):
+            _lib.check(L.tgcn_set_tuning(b"x3_tail", tail))
+            outs.append(F.cheb_project([_dev(t) for t in terms], _dev(W), _dev(bias), 1, M))
+    finally:
+        _lib.check(L.tgcn_set_tuning(b"x3_tail", 1))
+        _lib.check(L.tgcn_set_tuning(b"project_variant", 0))
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0].cpu().numpy(), ref) <= TOL

@@ -443,36 +443,30 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
 // go global -> registers -> split -> MFMA operand with no LDS round trip and no barrier; only the W tile (shared by the
 // 8 waves) is split into LDS, double-buffered, ONE barrier per 32-k tile.  A lane loads the 8 consecutive k of its row
 // as two float4 (the four k groups of a row are adjacent: whole 128-byte lines per row).
-template <int NT>
-__global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
-  constexpr int XT = 512, BM = 256, KT = 32, RS = KT;
+template <int NT, int RT>
+__device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* lds_raw, const int64_t m0, const int n0) {
+  constexpr int XT = 512, KT = 32, RS = KT;          // 8 waves x RT 16-row MFMA tiles: 128 * RT rows per workgroup
   constexpr int NW = NT * 16;
   constexpr int WPAIRS = (KT / 2 * NW + XT - 1) / XT;
   constexpr int WBUF = 3 * NW * RS;                                   // bf16 elements of one W buffer (3 planes)
   constexpr int ES = NW + 4;                                          // epilogue scratch row stride (floats)
-  constexpr int LDS_BYTES = (2 * WBUF * 2 > 8 * 16 * ES * 4) ? 2 * WBUF * 2 : 8 * 16 * ES * 4;
-  __shared__ __align__(16) unsigned char lds_raw[LDS_BYTES];
   unsigned short* Wp = reinterpret_cast<unsigned short*>(lds_raw);    // [2][3][NW * RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * NW;
-  f32x4 acc[2][NT];
+  f32x4 acc[RT][NT];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ktiles = (p.Kc + KT - 1) / KT;
   const int total = p.nterms * ktiles;
   // per-lane, tile-invariant parts of every address (the loop below adds only wave-uniform tile offsets: the vector ALU
   // is the co-bottleneck of this kernel -- an MFMA holds vector issue for 8 of its 16 cycles)
-  int64_t arow[2];                                   // element offset of this lane's 8 k inside row r (without lda * row: see aoff)
-  int64_t rowc[2];
+  int64_t rowc[RT];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int64_t m = m0 + wave * 32 + r * 16 + r16;
+  for (int r = 0; r < RT; ++r) {
+    const int64_t m = m0 + wave * (16 * RT) + r * 16 + r16;
     rowc[r] = m < p.M ? m : p.M - 1;                 // rows past the end re-read the last row; their results are never stored
-    arow[r] = 0;
   }
   int wsrc[WPAIRS], wdst[WPAIRS], wkk[WPAIRS];
   bool wcol[WPAIRS];
@@ -485,14 +479,14 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
     wsrc[h] = kk * p.N + (n0 + cc < p.N ? n0 + cc : 0);
     wdst[h] = cc * RS + x3_chunk(cc, kk >> 3) * 8 + (kk & 7);
   }
-  float ra[2][8], rw[2 * WPAIRS];
-  auto load_a = [&](int ti, float (&dst)[2][8]) {
+  float ra[RT][8], rw[2 * WPAIRS];
+  auto load_a = [&](int ti, float (&dst)[RT][8]) {
     const int term = ti / ktiles, k0 = (ti % ktiles) * KT;           // wave-uniform
     const float* __restrict__ A = p.a[term] + k0 + kg * 8;
     const int64_t lda = p.lda[term];
     if (k0 + KT <= p.Kc) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rowc[r]) * lda + h * 4);
@@ -500,7 +494,7 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
         }
     } else {                                                         // last k tile of a term: k past Kc reads as zero
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const bool ok = k0 + kg * 8 + h * 4 < p.Kc;
@@ -545,12 +539,12 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
   __syncthreads();
   const int frag = r16 * RS + x3_chunk(r16, kg) * 8;
   for (int ti = 0; ti < total; ++ti) {
-    float rn[2][8];
+    float rn[RT][8];
     const bool more = ti + 1 < total;
     if (more) { load_a(ti + 1, rn); load_w(ti + 1); }
-    bf16x8 a[2][3];
+    bf16x8 a[RT][3];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < RT; ++r) {
       unsigned pl[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) split3(ra[r][2 * j], ra[r][2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
@@ -566,26 +560,29 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
       bf16x8 w[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) w[q] = *reinterpret_cast<const bf16x8*>(&W0[q * NW * RS + (nt * 16) * RS + frag]);
-      // smallest terms first; the two row tiles alternate so that consecutive MFMAs are independent
-      f32x4 c0 = acc[0][nt], c1 = acc[1][nt];
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][2], w[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][2], w[0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], w[1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], w[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[2], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[2], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], w[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], w[0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], w[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], w[0], c1, 0, 0, 0);
-      acc[0][nt] = c0; acc[1][nt] = c1;
+      // smallest terms first; the row tiles of a wave alternate so that consecutive MFMAs are independent
+      f32x4 c[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) c[r] = acc[r][nt];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) c[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][2], w[0], c[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) c[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[1], c[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) c[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[2], c[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) c[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[0], c[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) c[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[1], c[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) c[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[0], c[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r][nt] = c[r];
     }
     if (more) {
       store_w((ti + 1) & 1);
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int j = 0; j < 8; ++j) ra[r][j] = rn[r][j];
     }
@@ -597,7 +594,7 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
       constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
       float* my = reinterpret_cast<float*>(lds_raw) + wave * (16 * ES);     // the loop ended with a barrier: W buffers are free
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < RT; ++r) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -605,7 +602,7 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
           const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
-          const int64_t m = m0 + wave * 32 + r * 16 + row;
+          const int64_t m = m0 + wave * (16 * RT) + r * 16 + row;
           const int col = n0 + seg;
           if (m >= p.M || col >= p.N) continue;
           float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
@@ -624,10 +621,10 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
     }
   }
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t m = m0 + wave * 32 + r * 16 + kg * 4 + i;
+      const int64_t m = m0 + wave * (16 * RT) + r * 16 + kg * 4 + i;
       if (m >= p.M) continue;
       const int64_t orow = proj_orow(p, m);
       const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
@@ -643,6 +640,19 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p) {
         *o = v;
       }
     }
+}
+
+// The workgroups of the LAST, partly filled round of 256-row tiles (one workgroup per CU: 218 VGPRs at NT = 10) would leave most
+// CUs idle for a whole tile time (90 k rows: 352 tiles = 256 + 96).  Their rows are handed out as 128-row tiles instead (one
+// 16-row MFMA tile per wave): twice as many workgroups of about half the duration, so the tail takes ~0.55 instead of 1 tile time.
+template <int NT>
+__global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p, const int main_blocks) {
+  constexpr int NW = NT * 16, WBUF = 3 * NW * 32, ES = NW + 4;
+  constexpr int LDS_BYTES = (2 * WBUF * 2 > 8 * 16 * ES * 4) ? 2 * WBUF * 2 : 8 * 16 * ES * 4;
+  __shared__ __align__(16) unsigned char lds_raw[LDS_BYTES];
+  const int bx = (int)blockIdx.x, n0 = blockIdx.y * NW;
+  if (bx < main_blocks) x3v2_body<NT, 2>(p, lds_raw, (int64_t)bx * 256, n0);
+  else x3v2_body<NT, 1>(p, lds_raw, (int64_t)main_blocks * 256 + (int64_t)(bx - main_blocks) * 128, n0);
 }
 
 // W-resident variant for the common case where the whole folded weight fits in LDS (nterms*Kc*N*4 <= 80 KB).

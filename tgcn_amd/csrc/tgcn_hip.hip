@@ -58,6 +58,7 @@ int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_narrow") == 0) { g_small_narrow.store(value); return TGCN_OK; }
   if (key && strcmp(key, "x3_form") == 0) { g_x3_form.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "x3_tail") == 0) { g_x3_tail.store(value != 0); return TGCN_OK; }
   if (key && strcmp(key, "overlap") == 0) { g_overlap.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
 }
@@ -315,8 +316,17 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     const int64_t gx3 = (M + 255) / 256 * p.nbatch;                   // sample-fastest: the nbatch workgroups of a tile are neighbours
     if (gx3 > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: grid too large");
     const dim3 grid3((unsigned)gx3, grid.y);
+    // project_x3v2_kernel runs one workgroup per CU: when the last round of 256-row tiles would fill at most ~60 % of the CUs,
+    // its rows go out as 128-row tiles (twice the workgroups, about half the duration each)
+    const int64_t B = (M + 255) / 256, rem = B % 256;
+    int64_t main_blocks = B, tail_blocks = 0;
+    if (rem != 0 && rem <= 160 && g_x3_tail.load()) {
+      main_blocks = B - rem;
+      tail_blocks = (M - main_blocks * 256 + 127) / 128;
+    }
+    const dim3 grid3v2((unsigned)(main_blocks + tail_blocks), grid.y);
 #define TGCN_PROJ3(NTV)                                                                              \
-  if (vec4 && NTV >= 6 && g_x3_form.load() == 2) hipLaunchKernelGGL((project_x3v2_kernel<NTV>), grid3, dim3(512), 0, st, p); /* wide outputs: compute-bound */ \
+  if (vec4 && NTV >= 6 && g_x3_form.load() == 2) hipLaunchKernelGGL((project_x3v2_kernel<NTV>), grid3v2, dim3(512), 0, st, p, (int)main_blocks); /* wide outputs: compute-bound */ \
   else if (vec4) hipLaunchKernelGGL((project_x3_kernel<NTV, true>), grid3, dim3(512), 0, st, p);      \
   else hipLaunchKernelGGL((project_x3_kernel<NTV, false>), grid3, dim3(512), 0, st, p);
     switch (nts) {
