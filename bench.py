@@ -80,8 +80,21 @@ def build_workload(name, labeling, device, n_override=None, nnz_override=None):
             spec = dict(cls="GCNCheb", q=128, H=1, f=1, g=64, K=5, desc="MNIST 8-NN grid n=784 nnz=6396, GCNCheb(L,1,64,5), q=128")
     else:
         raise SystemExit("unknown workload " + name)
+    # one-off operand construction, timed for the record (not part of a step): COO -> CSR, then the hop schedule of the layer's row width
+    from tgcn_amd import graph as _graph, _lib as _l
+    sync = (lambda: torch.cuda.synchronize()) if torch.device(device).type == "cuda" else (lambda: None)
+    sync()
+    t0 = time.perf_counter()
     op = GraphOperand.from_coo(n, row, col, val, device)
+    sync()
+    t1 = time.perf_counter()
     del row, col, val
+    spec["operand_build"] = dict(builder=_graph.BUILDER if torch.device(device).type == "cuda" else "torch", csr_ms=round((t1 - t0) * 1e3, 2))
+    if torch.device(device).type == "cuda":
+        C_row = spec["H"] * spec["f"]
+        op.schedule_for(C_row if C_row >= 32 or spec["q"] == 1 else spec["q"] * C_row, True)
+        sync()
+        spec["operand_build"]["schedule_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
     return op, spec
 
 
@@ -531,6 +544,7 @@ def main():
                                 sharding=(("%d group(s) x %d vertex shards, %s exchange per hop inside a group" % (ngroups, sh.world, sh.exchange)) if ngroups > 1 else ("vertex rows across ranks, %s exchange per hop" % sh.exchange)) if vertex_mode else (("the %d time steps of the workload split over %d ranks (%d on rank 0), CSR replicated, no collective" % (q_total, world, q) if strong_time else "%d time steps per rank, CSR replicated, no collective" % q) if world > 1 else "single GPU"),
                                 nnz=op.nnz, n=op.n,
                                 arithmetic="f32 (bf16x3 projection: fp32 operands split into three bf16 terms on the matrix pipe)" if x3_proj else "f32",
+                                operand_build=spec.get("operand_build"),
                                 empty_rows=(plan.n_empty if plan is not None else 0),
                                 hop_tensors="compact (%d of %d vertices have stored entries)" % (plan.n_c, op.n) if plan is not None else "all vertices"),
                     roofline=roofline, cpu_baseline=cpu)

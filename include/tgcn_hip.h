@@ -89,9 +89,10 @@ const char* tgcn_last_error(void);
 int tgcn_abi_version(void);
 
 /* Operand and schedule construction inside the library (tgcn_graph_create_from_coo/csr, tgcn_graph_destroy),
- * so that a caller of the C ABI needs nothing from the Python package.  These are the ONLY entry points that allocate
- * device memory and synchronise (they copy the index arrays to the host, sort and scan there, and upload the result):
- * call them once per graph, outside the forward path.  All index / value pointers are DEVICE pointers like everywhere else.
+ * so that a caller of the C ABI needs nothing from the Python package.  The work runs ON THE DEVICE in kernels of this library
+ * (csrc/device_build.h: stable LSD radix sort, prefix sums, binary-search marks -- no host round trip of the index arrays);
+ * these are the ONLY entry points that allocate device memory and synchronise (a few 8-byte read-backs that size the next
+ * allocation): call them once per graph, outside the forward path.  All index / value pointers are DEVICE pointers.
  *   from_coo         entries in any order; duplicates of one (row, col) stay separate entries in their given order (their
  *                    sum is what scatter_add computes, gcn.py:308,343)
  *   from_csr         the same from row pointers (int64, rowptr[n] = nnz)
@@ -111,6 +112,20 @@ const tgcn_csr* tgcn_graph_csr(const tgcn_graph* g);
 int64_t tgcn_graph_n_cols(const tgcn_graph* g);
 void tgcn_graph_destroy(tgcn_graph* g);
 int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched** out);
+/* The same schedule for a CSR the caller owns (n_cols = number of columns of the operand). */
+int tgcn_sched_build_csr(const tgcn_csr* A, int64_t n_cols, int32_t C, int aligned16, tgcn_sched** out);
+/* The arrays of a library-built schedule copied (device to device) into arrays the caller owns, sized from the counts of
+ * tgcn_sched_get: blk_row [nblk+1], seg_row / seg_e0 / seg_e1 / seg_slot [max(nseg, 1)], long_row [max(nlong, 1)],
+ * long_slot [max(nlong + 1, 2)].  Lets a host side that manages its own memory (tgcn_amd/graph.py) drop the handle afterwards. */
+int tgcn_sched_copy(const tgcn_sched* s, void* stream, int32_t* blk_row, int32_t* seg_row, int32_t* seg_e0, int32_t* seg_e1,
+                    int32_t* seg_slot, int32_t* long_row, int32_t* long_slot);
+/* COO -> CSR into CALLER memory on `stream` (what tgcn_graph_create_from_coo does into memory of its own): rowptr [n+1] int32 and
+ * packed entries [nnz], rows sorted by (row, col), duplicates in their given order.  Device kernels of this library (two stable
+ * radix sorts, a prefix sum); synchronises the stream once (range check of the indices).  workspace: 256-byte aligned,
+ * tgcn_csr_build_workspace_bytes(n, nnz). */
+size_t tgcn_csr_build_workspace_bytes(int64_t n, int64_t nnz);
+int tgcn_csr_build_f32(void* stream, int64_t n, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col, const float* val,
+                       int32_t* rowptr, tgcn_edge* edges, void* workspace, size_t workspace_bytes);
 
 /* One level of the reference's Graclus / METIS-style coarsening (gcn/coarsening.py:119-165: a Python loop over vertices and
  * entries) as host code: HOST arrays in and out -- coarsening is one-off preprocessing of the caller's graph (tgcn_amd/

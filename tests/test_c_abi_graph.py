@@ -107,7 +107,9 @@ def test_library_schedule_equals_the_python_builder(lib, n):
         s = C.c_void_p()
         _ok(lib, lib.tgcn_sched_build(g, C.c_int32(C_row), C.c_int(1), C.byref(s)))
         mine = C.cast(lib.tgcn_sched_get(s), C.POINTER(SchedStruct)).contents
-        py = op.schedule_for(C_row, True)
+        from tgcn_amd.graph import Schedule
+        lanes = lib.tgcn_hop_lanes_per_row(C_row, 1)
+        py = Schedule(op.rowptr, op.n, lanes, edges=op.edges, builder="torch")        # the torch index-op builder: the cross-check
         for f in ("lanes_per_row", "row_thresh", "nblk", "nseg", "nlong", "nhuge", "npartial", "seg_mode"):
             assert getattr(mine, f) == getattr(py.struct, f), f
         for f, cnt in (("blk_row", py.nblk + 1), ("seg_row", py.nseg), ("seg_e0", py.nseg), ("seg_e1", py.nseg), ("seg_slot", py.nseg),

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libtgcn_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "tgcn_hip.hip")]      # one translation unit; the kernels are in csrc/*.h
-HEADERS = [os.path.join(_HERE, "csrc", h) for h in ("common.h", "hop.h", "project.h", "wgrad.h", "small_graph.h", "pool_relayout.h", "graph_build.h")]
+HEADERS = [os.path.join(_HERE, "csrc", h) for h in ("common.h", "hop.h", "project.h", "wgrad.h", "small_graph.h", "pool_relayout.h", "device_build.h", "graph_build.h")]
 INCLUDE = os.path.join(ROOT, "include")
 
 
@@ -45,6 +45,10 @@ SIGNATURES = {
     "tgcn_graclus_match_f32": (C.c_int, [C.c_int64, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "tgcn_graclus_match_f64": (C.c_int, [C.c_int64, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "tgcn_sched_build": (C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(_P)]),
+    "tgcn_sched_build_csr": (C.c_int, [C.POINTER(CsrStruct), C.c_int64, C.c_int32, C.c_int, C.POINTER(_P)]),
+    "tgcn_sched_copy": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tgcn_csr_build_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "tgcn_csr_build_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_size_t]),
     "tgcn_sched_get": (C.POINTER(SchedStruct), [_P]),
     "tgcn_sched_destroy": (None, [_P]),
     "tgcn_profile_start": (C.c_int, [C.c_int32]),

@@ -1,19 +1,22 @@
-// graph_build.h -- one-off construction of the sparse operand and its work schedule inside the library, so that the C ABI
-// is usable without the Python package (include/tgcn_hip.h: tgcn_graph_*, tgcn_sched_*).  Host code: the arrays are copied
-// from the device, sorted / scanned here and uploaded again -- the only entry points that allocate and synchronise; they
-// run once per operand, never on the forward path.  The schedule is the one tgcn_amd/graph.py::Schedule builds (row blocks +
-// column-ordered segments; tests/test_c_abi_graph.py compares the two array by array).
+// graph_build.h -- construction of the sparse operand and its work schedule inside the library, so that the C ABI is usable
+// without the Python package (include/tgcn_hip.h: tgcn_graph_*, tgcn_sched_*, tgcn_csr_build_f32).  The work is done ON THE DEVICE
+// by the kernels of device_build.h (stable radix sort, prefix sums, binary-search marks); this file is their host-side
+// orchestration.  tgcn_graph_create_* / tgcn_sched_build* are the only entry points that allocate device memory and synchronise
+// (a handful of 8-byte read-backs: totals that size the next allocation); they run once per operand, never on the forward path.
+// The schedule is the one tgcn_amd/graph.py::Schedule builds with torch index ops (row blocks + column-ordered segments), which
+// stays as the cross-check: tests/test_c_abi_graph.py and tests/test_device_build.py compare the two array by array.
 // Part of the single translation unit tgcn_hip.hip (included once, inside its anonymous namespace).
 #pragma once
 
 struct DeviceBuf {
   void* p = nullptr;
   ~DeviceBuf() { if (p) (void)hipFree(p); }
-  int upload(const void* host, size_t bytes) {
+  int alloc(size_t bytes) {
+    if (p) { (void)hipFree(p); p = nullptr; }
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { p = nullptr; return -1; }
-    if (bytes && hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return -1;
     return 0;
   }
+  int zero(size_t bytes) { return (alloc(bytes) || hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess) ? -1 : 0; }
 };
 
 }  // namespace (the opaque handle types are named by the header)
@@ -22,8 +25,6 @@ struct tgcn_graph {
   tgcn_csr csr;
   int64_t n_cols;
   DeviceBuf rowptr, edges;
-  std::vector<int32_t> h_rowptr;        // host copies: schedules are built from them
-  std::vector<tgcn_edge> h_edges;
 };
 
 struct tgcn_sched {
@@ -34,73 +35,92 @@ struct tgcn_sched {
 namespace {
 
 template <typename T>
-int fetch(std::vector<T>& dst, const T* dev, size_t count) {
-  dst.resize(count);
-  if (count && hipMemcpy(dst.data(), dev, count * sizeof(T), hipMemcpyDefault) != hipSuccess) return -1;   // device (the convention) or host memory
-  return 0;
-}
-
-// rows sorted by (row, col), duplicates kept as separate entries in their given order (their sum is what scatter_add
-// computes, tgcn/nn/gcn.py:308,343)
-int graph_from_host_coo(int64_t n, int64_t n_cols, const std::vector<int64_t>& row, const std::vector<int64_t>& col,
-                        const std::vector<float>& val, tgcn_graph** out) {
-  const size_t nnz = row.size();
-  for (size_t e = 0; e < nnz; ++e)
-    if (row[e] < 0 || row[e] >= n || col[e] < 0 || col[e] >= n_cols)
-      TGCN_FAIL(TGCN_ERR_INVALID, "graph: vertex index outside [0, %lld) x [0, %lld)", (long long)n, (long long)n_cols);
-  std::vector<int64_t> order(nnz);
-  std::iota(order.begin(), order.end(), (int64_t)0);
-  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return row[a] != row[b] ? row[a] < row[b] : col[a] < col[b]; });
-  tgcn_graph* g = new (std::nothrow) tgcn_graph();
-  if (!g) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph: out of host memory");
-  g->h_rowptr.assign(n + 1, 0);
-  for (size_t e = 0; e < nnz; ++e) g->h_rowptr[row[e] + 1]++;
-  for (int64_t i = 0; i < n; ++i) g->h_rowptr[i + 1] += g->h_rowptr[i];
-  g->h_edges.resize(nnz ? nnz : 1);
-  for (size_t e = 0; e < nnz; ++e) { g->h_edges[e].col = (int32_t)col[order[e]]; g->h_edges[e].val = val[order[e]]; }
-  if (g->rowptr.upload(g->h_rowptr.data(), (n + 1) * sizeof(int32_t)) || g->edges.upload(g->h_edges.data(), g->h_edges.size() * sizeof(tgcn_edge))) {
-    delete g;
-    TGCN_FAIL(TGCN_ERR_LAUNCH, "graph: device allocation / upload failed");
-  }
-  g->csr.n = n; g->csr.nnz = (int64_t)nnz; g->csr.rowptr = (const int32_t*)g->rowptr.p; g->csr.edges = (const tgcn_edge*)g->edges.p;
-  g->csr.dense = nullptr;
-  g->n_cols = n_cols;
-  *out = g;
-  return TGCN_OK;
+int read_back(T* dst, const T* dev) {      // one value of a device array (sizes the next step)
+  return hipMemcpy(dst, dev, sizeof(T), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 inline bool graph_sizes_ok(int64_t n, int64_t n_cols, int64_t nnz) {
   return n > 0 && n_cols > 0 && nnz >= 0 && n < (int64_t)INT32_MAX && n_cols < (int64_t)INT32_MAX && nnz < (int64_t)INT32_MAX - 1;
 }
 
+// rows sorted by (row, col), duplicates kept as separate entries in their given order (their sum is what scatter_add computes,
+// tgcn/nn/gcn.py:308,343): csr_build_device into arrays the handle owns
+int graph_from_device_coo(int64_t n, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col, const float* val, tgcn_graph** out) {
+  tgcn_graph* g = new (std::nothrow) tgcn_graph();
+  if (!g) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph: out of host memory");
+  DeviceBuf ws;
+  if (g->rowptr.alloc((size_t)(n + 1) * sizeof(int32_t)) || g->edges.alloc((size_t)(nnz ? nnz : 1) * sizeof(tgcn_edge)) ||
+      ws.alloc(csr_build_ws_bytes(n, nnz))) {
+    delete g;
+    TGCN_FAIL(TGCN_ERR_LAUNCH, "graph: device allocation failed");
+  }
+  const int rc = csr_build_device((hipStream_t)0, n, n_cols, nnz, row, col, val, (int32_t*)g->rowptr.p, (tgcn_edge*)g->edges.p, (char*)ws.p);
+  if (rc != TGCN_OK || hipStreamSynchronize((hipStream_t)0) != hipSuccess) {
+    delete g;
+    if (rc == TGCN_OK) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph: build failed on the device");
+    return rc;
+  }
+  g->csr.n = n; g->csr.nnz = nnz; g->csr.rowptr = (const int32_t*)g->rowptr.p; g->csr.edges = (const tgcn_edge*)g->edges.p;
+  g->csr.dense = nullptr;
+  g->n_cols = n_cols;
+  *out = g;
+  return TGCN_OK;
+}
+
+// rows[e] = row of entry e of a CSR given by int64 row pointers (last rp[i] <= e)
+__global__ void expand_rows_kernel(const int64_t* __restrict__ rp, int64_t n, int64_t nnz, int64_t* __restrict__ rows, int* __restrict__ bad) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n;                         // first i with rp[i + 1] > e
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rp[mid + 1] <= e) lo = mid + 1; else hi = mid; }
+    if (lo >= n) { *bad = 1; lo = n - 1; }
+    rows[e] = lo;
+  }
+}
+
+__global__ void rowptr_check_kernel(const int64_t* __restrict__ rp, int64_t n, int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (rp[i + 1] < rp[i] || (i == 0 && rp[0] != 0)) *bad = 1;
+}
+
+__global__ void i32_to_i64_kernel(const int32_t* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
 }  // namespace
 
 extern "C" {
 
+size_t tgcn_csr_build_workspace_bytes(int64_t n, int64_t nnz) { return (n > 0 && nnz >= 0) ? csr_build_ws_bytes(n, nnz) : 0; }
+
+int tgcn_csr_build_f32(void* stream, int64_t n, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col, const float* val,
+                       int32_t* rowptr, tgcn_edge* edges, void* workspace, size_t workspace_bytes) {
+  if (!graph_sizes_ok(n, n_cols, nnz) || !rowptr || (nnz > 0 && (!row || !col || !val || !edges))) TGCN_FAIL(TGCN_ERR_INVALID, "csr_build: bad argument");
+  if (!workspace || workspace_bytes < csr_build_ws_bytes(n, nnz) || ((uintptr_t)workspace & 255)) TGCN_FAIL(TGCN_ERR_WORKSPACE, "csr_build: workspace %zu < %zu (256-byte aligned)", workspace_bytes, csr_build_ws_bytes(n, nnz));
+  return csr_build_device((hipStream_t)stream, n, n_cols, nnz, row, col, val, rowptr, edges, (char*)workspace);
+}
+
 int tgcn_graph_create_from_coo(int64_t n, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col, const float* val,
                                tgcn_graph** out) {
   if (!out || !graph_sizes_ok(n, n_cols, nnz) || (nnz > 0 && (!row || !col || !val))) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_coo: bad argument");
-  std::vector<int64_t> r, c;
-  std::vector<float> v;
-  if (fetch(r, row, (size_t)nnz) || fetch(c, col, (size_t)nnz) || fetch(v, val, (size_t)nnz)) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_coo: device read failed");
-  return graph_from_host_coo(n, n_cols, r, c, v, out);
+  return graph_from_device_coo(n, n_cols, nnz, row, col, val, out);
 }
 
 int tgcn_graph_create_from_csr(int64_t n, int64_t n_cols, const int64_t* rowptr, const int32_t* col, const float* val, tgcn_graph** out) {
   if (!out || !rowptr || n <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_csr: bad argument");
-  std::vector<int64_t> rp;
-  if (fetch(rp, rowptr, (size_t)n + 1)) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_csr: device read failed");
-  const int64_t nnz = rp[n];
-  if (!graph_sizes_ok(n, n_cols, nnz) || rp[0] != 0 || (nnz > 0 && (!col || !val))) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_csr: bad rowptr");
-  std::vector<int32_t> c32;
-  std::vector<float> v;
-  if (fetch(c32, col, (size_t)nnz) || fetch(v, val, (size_t)nnz)) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_csr: device read failed");
-  std::vector<int64_t> r((size_t)nnz), c((size_t)nnz);
-  for (int64_t i = 0; i < n; ++i) {
-    if (rp[i + 1] < rp[i]) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_csr: rowptr decreases at row %lld", (long long)i);
-    for (int64_t e = rp[i]; e < rp[i + 1]; ++e) { r[e] = i; c[e] = c32[e]; }
+  int64_t nnz = 0, first = 0;
+  if (read_back(&nnz, rowptr + n) || read_back(&first, rowptr)) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_csr: device read failed");
+  if (!graph_sizes_ok(n, n_cols, nnz) || first != 0 || (nnz > 0 && (!col || !val))) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_csr: bad rowptr");
+  DeviceBuf rows, cols, bad;
+  if (rows.alloc((size_t)(nnz ? nnz : 1) * 8) || cols.alloc((size_t)(nnz ? nnz : 1) * 8) || bad.zero(sizeof(int))) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_csr: device allocation failed");
+  hipLaunchKernelGGL(rowptr_check_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, (hipStream_t)0, rowptr, n, (int*)bad.p);
+  if (nnz > 0) {
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_1d(nnz)), dim3(kBlock), 0, (hipStream_t)0, rowptr, n, nnz, (int64_t*)rows.p, (int*)bad.p);
+    hipLaunchKernelGGL(i32_to_i64_kernel, dim3(grid_1d(nnz)), dim3(kBlock), 0, (hipStream_t)0, col, (int64_t*)cols.p, nnz);
   }
-  return graph_from_host_coo(n, n_cols, r, c, v, out);
+  int h_bad = 0;
+  if (read_back(&h_bad, (const int*)bad.p)) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_csr: device read failed");
+  if (h_bad) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_csr: rowptr is not a non-decreasing sequence from 0 to nnz");
+  return graph_from_device_coo(n, n_cols, nnz, (const int64_t*)rows.p, (const int64_t*)cols.p, val, out);
 }
 
 /* ChebConv / ChebTimeConv operand from the caller's edge list (tgcn/nn/gcn.py:398-413 == :495-510): self loops removed,
@@ -108,101 +128,105 @@ int tgcn_graph_create_from_csr(int64_t n, int64_t n_cols, const int64_t* rowptr,
  * vertices without outgoing edges. */
 int tgcn_graph_create_from_edge_index(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_weight, tgcn_graph** out) {
   if (!out || !graph_sizes_ok(n, n, E) || (E > 0 && !edge_index)) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_edge_index: bad argument");
-  std::vector<int64_t> ei;
-  std::vector<float> w;
-  if (fetch(ei, edge_index, (size_t)(2 * E)) || (edge_weight && fetch(w, edge_weight, (size_t)E))) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_edge_index: device read failed");
-  std::vector<int64_t> r, c;
-  std::vector<float> v;
-  std::vector<float> deg((size_t)n, 0.f);
-  for (int64_t e = 0; e < E; ++e) {
-    const int64_t a = ei[e], b = ei[E + e];
-    if (a < 0 || a >= n || b < 0 || b >= n) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_edge_index: vertex index outside [0, %lld)", (long long)n);
-    if (a == b) continue;
-    r.push_back(a); c.push_back(b); v.push_back(edge_weight ? w[e] : 1.f);
-    deg[a] += 1.f;
+  hipStream_t st = (hipStream_t)0;
+  DeviceBuf keep, pos, scanws, r, c, v, deg, bad;
+  const size_t m1 = (size_t)(E ? E : 1);
+  if (keep.alloc((m1 + 1) * 8) || pos.alloc((m1 + 1) * 8) || scanws.alloc(scan_ws_elems(E + 1) * 8) || r.alloc(m1 * 8) || c.alloc(m1 * 8) ||
+      v.alloc(m1 * 4) || deg.zero((size_t)n * 4) || bad.zero(sizeof(int)) || hipMemset(keep.p, 0, (m1 + 1) * 8) != hipSuccess)
+    TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_edge_index: device allocation failed");
+  int64_t kept = 0;
+  if (E > 0) {
+    hipLaunchKernelGGL(edge_keep_kernel, dim3(grid_1d(E)), dim3(kBlock), 0, st, edge_index, E, n, (int64_t*)keep.p, (int*)bad.p);
+    scan_i64(st, (const int64_t*)keep.p, (int64_t*)pos.p, E + 1, 0, (int64_t*)scanws.p);          // pos[E] = number of kept edges
+    int h_bad = 0;
+    if (read_back(&h_bad, (const int*)bad.p) || read_back(&kept, (const int64_t*)pos.p + E)) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_edge_index: device read failed");
+    if (h_bad) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_edge_index: vertex index outside [0, %lld)", (long long)n);
+    hipLaunchKernelGGL(edge_compact_kernel, dim3(grid_1d(E)), dim3(kBlock), 0, st, edge_index, edge_weight, E, (const int64_t*)keep.p,
+                       (const int64_t*)pos.p, (int64_t*)r.p, (int64_t*)c.p, (float*)v.p, (unsigned int*)deg.p);
+    if (kept > 0)
+      hipLaunchKernelGGL(edge_normalise_kernel, dim3(grid_1d(kept)), dim3(kBlock), 0, st, (const int64_t*)r.p, (const int64_t*)c.p, (float*)v.p,
+                         (const unsigned int*)deg.p, kept);
   }
-  std::vector<float> dis((size_t)n);
-  for (int64_t i = 0; i < n; ++i) dis[i] = deg[i] > 0.f ? 1.0f / sqrtf(deg[i]) : 0.f;
-  for (size_t e = 0; e < r.size(); ++e) v[e] = -dis[r[e]] * v[e] * dis[c[e]];
-  return graph_from_host_coo(n, n, r, c, v, out);
+  return graph_from_device_coo(n, n, kept, (const int64_t*)r.p, (const int64_t*)c.p, (const float*)v.p, out);
 }
 
 const tgcn_csr* tgcn_graph_csr(const tgcn_graph* g) { return g ? &g->csr : nullptr; }
 int64_t tgcn_graph_n_cols(const tgcn_graph* g) { return g ? g->n_cols : 0; }
 void tgcn_graph_destroy(tgcn_graph* g) { delete g; }
 
-/* Row-block + column-ordered-segment schedule of `g` for rows of C floats (the arrays documented at tgcn_csr_sched). */
-int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched** out) {
-  if (!g || !out || C <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "sched_build: bad argument");
+/* Row-block + column-ordered-segment schedule of a CSR operand for rows of C floats (the arrays documented at tgcn_csr_sched),
+ * built on the device. */
+int tgcn_sched_build_csr(const tgcn_csr* A, int64_t n_cols, int32_t C, int aligned16, tgcn_sched** out) {
+  if (!A || !out || C <= 0 || A->n <= 0 || !A->rowptr || (A->nnz > 0 && !A->edges) || n_cols <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "sched_build: bad argument");
   const int lanes = hop_geom(C, aligned16).lpr;
   const int gpb = kBlock / lanes;
-  const int64_t n = g->csr.n;
+  const int64_t n = A->n;
   const int32_t seg_mode = 0;                             // lane-group segments, as tgcn_amd/graph.py::SEG_MODE (wave segments measured slower on cfg5)
-  const int32_t row_thresh = 32, seg_len = seg_mode == 1 ? 32 * (64 / lanes) : 32, huge_slots = 64, row_cost = 4;
+  const int32_t row_thresh = 32, seg_len = 32, huge_slots = 64, row_cost = 4;
   const int64_t max_blocks_hint = 2048;
-  const std::vector<int32_t>& rp = g->h_rowptr;
-  // ---- short rows: nnz-balanced row blocks (cost = entries + 4 per row; long rows cost 4)
-  std::vector<int64_t> cum((size_t)n);
-  int64_t total = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t d = rp[i + 1] - rp[i];
-    total += (d > row_thresh ? 0 : d) + row_cost;
-    cum[i] = total;
-  }
+  hipStream_t st = (hipStream_t)0;
+  tgcn_sched* sc = new (std::nothrow) tgcn_sched();
+  if (!sc) TGCN_FAIL(TGCN_ERR_LAUNCH, "sched_build: out of host memory");
+#define TGCN_SCHED_FAIL(...) do { delete sc; TGCN_FAIL(TGCN_ERR_LAUNCH, __VA_ARGS__); } while (0)
+  // ---- short rows: nnz-balanced row blocks (cost = entries + 4 per row; rows cut into segments cost 4)
+  DeviceBuf cost, is_seg, pos, scanws;
+  if (cost.alloc((size_t)n * 8) || is_seg.alloc((size_t)(n + 1) * 8) || pos.alloc((size_t)(n + 1) * 8) || scanws.alloc(scan_ws_elems(n + 1) * 8) ||
+      hipMemset(is_seg.p, 0, (size_t)(n + 1) * 8) != hipSuccess)
+    TGCN_SCHED_FAIL("sched_build: device allocation failed");
+  hipLaunchKernelGGL(sched_cost_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, st, A->rowptr, n, (int)row_thresh, (int)row_cost, (int64_t*)cost.p, (int64_t*)is_seg.p);
+  scan_i64(st, (const int64_t*)cost.p, (int64_t*)cost.p, n, 1, (int64_t*)scanws.p);                   // cum = inclusive prefix sum
+  scan_i64(st, (const int64_t*)is_seg.p, (int64_t*)pos.p, n + 1, 0, (int64_t*)scanws.p);              // pos[n] = rows cut into segments
+  int64_t total = 0, m = 0;
+  if (read_back(&total, (const int64_t*)cost.p + (n - 1)) || read_back(&m, (const int64_t*)pos.p + n)) TGCN_SCHED_FAIL("sched_build: device read failed");
   const int64_t cap = lanes <= 16 ? 64 : 256;        // narrow rows: small blocks keep an XCD's gather window inside its L2 (tgcn_amd/graph.py)
   const int64_t target = std::max<int64_t>(gpb * 16, std::min<int64_t>(gpb * cap, (total + max_blocks_hint - 1) / max_blocks_hint));
   const int64_t nblk = std::max<int64_t>(1, (total + target - 1) / target);
-  std::vector<int32_t> blk_row;
-  blk_row.push_back(0);
-  for (int64_t b = 1; b < nblk; ++b) {
-    const int64_t mark = b * target;
-    const int64_t pos = std::lower_bound(cum.begin(), cum.end(), mark) - cum.begin();      // searchsorted(cum, mark)
-    blk_row.push_back((int32_t)std::min<int64_t>(pos + 1, n));
-  }
-  blk_row.push_back((int32_t)n);
+  if (sc->blk_row.alloc((size_t)(nblk + 1) * 4)) TGCN_SCHED_FAIL("sched_build: device allocation failed");
+  hipLaunchKernelGGL(sched_marks_kernel, dim3(grid_1d(nblk + 1)), dim3(kBlock), 0, st, (const int64_t*)cost.p, n, target, nblk, (int32_t*)sc->blk_row.p);
   // ---- longer rows: segments; rows with several segments ("long") first, by decreasing segment count (stable)
-  std::vector<int64_t> seg_rows;
-  for (int64_t i = 0; i < n; ++i) if (rp[i + 1] - rp[i] > row_thresh) seg_rows.push_back(i);
-  std::vector<int64_t> nsegs(seg_rows.size());
-  for (size_t i = 0; i < seg_rows.size(); ++i) nsegs[i] = (rp[seg_rows[i] + 1] - rp[seg_rows[i]] + seg_len - 1) / seg_len;
-  std::vector<size_t> ord(seg_rows.size());
-  std::iota(ord.begin(), ord.end(), (size_t)0);
-  std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return nsegs[a] > nsegs[b]; });
-  std::vector<int32_t> seg_row, seg_e0, seg_e1, seg_slot, long_row, long_slot;
   int64_t nlong = 0, nhuge = 0, npartial = 0, nseg = 0;
-  for (size_t i : ord) { if (nsegs[i] > 1) { ++nlong; npartial += nsegs[i]; } if (nsegs[i] > huge_slots) ++nhuge; nseg += nsegs[i]; }
-  std::vector<int64_t> key;
-  {
-    int64_t slot = 0;
-    for (size_t i : ord) {
-      const int64_t r = seg_rows[i];
-      if (nsegs[i] > 1) { long_row.push_back((int32_t)r); long_slot.push_back((int32_t)slot); }
-      for (int64_t s = 0; s < nsegs[i]; ++s, ++slot) {
-        const int64_t e0 = rp[r] + s * seg_len, e1 = std::min<int64_t>(e0 + seg_len, rp[r + 1]);
-        seg_row.push_back((int32_t)r); seg_e0.push_back((int32_t)e0); seg_e1.push_back((int32_t)e1);
-        seg_slot.push_back(slot < npartial ? (int32_t)slot : -1);
-        key.push_back(g->h_edges[e0].col);
-      }
-    }
-    if (nlong) long_slot.push_back((int32_t)npartial);
+  if (m > 0) {
+    const uint32_t max_key = (uint32_t)((A->nnz + seg_len - 1) / seg_len + 1);
+    DeviceBuf seg_rows, key, sortws, nsegs, first, cnt2;
+    if (seg_rows.alloc((size_t)m * 4) || key.alloc((size_t)m * 4) || sortws.alloc(sort_ws_bytes(m)) || nsegs.zero((size_t)(m + 1) * 8) ||
+        first.alloc((size_t)(m + 1) * 8) || cnt2.alloc(16))
+      TGCN_SCHED_FAIL("sched_build: device allocation failed");
+    hipLaunchKernelGGL(sched_longrows_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, st, A->rowptr, n, (const int64_t*)is_seg.p, (const int64_t*)pos.p,
+                       (int)seg_len, max_key, (uint32_t*)seg_rows.p, (uint32_t*)key.p);
+    radix_sort_pairs(st, (uint32_t*)key.p, (uint32_t*)seg_rows.p, m, bits_for((int64_t)max_key + 1), (char*)sortws.p);
+    hipLaunchKernelGGL(sched_nsegs_kernel, dim3(grid_1d(m)), dim3(kBlock), 0, st, (const uint32_t*)key.p, max_key, m, (int64_t*)nsegs.p);
+    hipLaunchKernelGGL(sched_counts_kernel, dim3(1), dim3(64), 0, st, (const int64_t*)nsegs.p, m, (int)huge_slots, (int64_t*)cnt2.p);
+    scan_i64(st, (const int64_t*)nsegs.p, (int64_t*)first.p, m + 1, 0, (int64_t*)scanws.p);             // first[m] = number of segments
+    int64_t h2[2] = {0, 0};
+    if (hipMemcpy(h2, cnt2.p, 16, hipMemcpyDeviceToHost) != hipSuccess || read_back(&nseg, (const int64_t*)first.p + m)) TGCN_SCHED_FAIL("sched_build: device read failed");
+    nlong = h2[0]; nhuge = h2[1];
+    if (nlong > 0 && read_back(&npartial, (const int64_t*)first.p + nlong)) TGCN_SCHED_FAIL("sched_build: device read failed");
+    if (nseg >= (int64_t)INT32_MAX) TGCN_SCHED_FAIL("sched_build: too many segments");
+    DeviceBuf u_row, u_e0, u_e1, u_slot, key2, ident, sortws2;
+    const size_t sb = (size_t)nseg * 4;
+    if (u_row.alloc(sb) || u_e0.alloc(sb) || u_e1.alloc(sb) || u_slot.alloc(sb) || key2.alloc(sb) || ident.alloc(sb) || sortws2.alloc(sort_ws_bytes(nseg)) ||
+        sc->seg_row.alloc(sb) || sc->seg_e0.alloc(sb) || sc->seg_e1.alloc(sb) || sc->seg_slot.alloc(sb) || sc->long_row.alloc((size_t)(nlong ? nlong : 1) * 4) ||
+        sc->long_slot.zero((size_t)(nlong + 2) * 4))
+      TGCN_SCHED_FAIL("sched_build: device allocation failed");
+    hipLaunchKernelGGL(sched_segments_kernel, dim3(grid_1d(nseg)), dim3(kBlock), 0, st, A->rowptr, A->edges, (const uint32_t*)seg_rows.p, (const int64_t*)first.p, m,
+                       nseg, npartial, (int)seg_len, (int32_t*)u_row.p, (int32_t*)u_e0.p, (int32_t*)u_e1.p, (int32_t*)u_slot.p, (uint32_t*)key2.p, (uint32_t*)ident.p);
+    // processing order: by first column (stable)
+    radix_sort_pairs(st, (uint32_t*)key2.p, (uint32_t*)ident.p, nseg, bits_for(n_cols), (char*)sortws2.p);
+    const unsigned gs = grid_1d(nseg);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_row.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_row.p, nseg);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_e0.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_e0.p, nseg);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_e1.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_e1.p, nseg);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_slot.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_slot.p, nseg);
+    if (nlong > 0)
+      hipLaunchKernelGGL(sched_long_kernel, dim3(grid_1d(nlong + 1)), dim3(kBlock), 0, st, (const uint32_t*)seg_rows.p, (const int64_t*)first.p, nlong, npartial,
+                         (int32_t*)sc->long_row.p, (int32_t*)sc->long_slot.p);
+    if (hipStreamSynchronize(st) != hipSuccess) TGCN_SCHED_FAIL("sched_build: kernels failed");      // the scratch buffers die with this scope
+  } else {
+    if (sc->seg_row.zero(4) || sc->seg_e0.zero(4) || sc->seg_e1.zero(4) || sc->seg_slot.zero(4) || sc->long_row.zero(4) || sc->long_slot.zero(8))
+      TGCN_SCHED_FAIL("sched_build: device allocation failed");
   }
-  // processing order: by first column (stable)
-  std::vector<size_t> perm((size_t)nseg);
-  std::iota(perm.begin(), perm.end(), (size_t)0);
-  std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
-  auto permute = [&](std::vector<int32_t>& v) { std::vector<int32_t> t(v.size()); for (size_t i = 0; i < v.size(); ++i) t[i] = v[perm[i]]; v.swap(t); };
-  permute(seg_row); permute(seg_e0); permute(seg_e1); permute(seg_slot);
-  if (seg_row.empty()) { seg_row.push_back(0); seg_e0.push_back(0); seg_e1.push_back(0); seg_slot.push_back(0); }
-  if (long_row.empty()) long_row.push_back(0);
-  if (long_slot.size() < 2) long_slot.assign(2, 0);
-  tgcn_sched* sc = new (std::nothrow) tgcn_sched();
-  if (!sc) TGCN_FAIL(TGCN_ERR_LAUNCH, "sched_build: out of host memory");
-  auto up = [&](DeviceBuf& b, const std::vector<int32_t>& v) { return b.upload(v.data(), v.size() * sizeof(int32_t)); };
-  if (up(sc->blk_row, blk_row) || up(sc->seg_row, seg_row) || up(sc->seg_e0, seg_e0) || up(sc->seg_e1, seg_e1) || up(sc->seg_slot, seg_slot) ||
-      up(sc->long_row, long_row) || up(sc->long_slot, long_slot)) {
-    delete sc;
-    TGCN_FAIL(TGCN_ERR_LAUNCH, "sched_build: device allocation / upload failed");
-  }
+  if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) TGCN_SCHED_FAIL("sched_build: kernels failed");
+#undef TGCN_SCHED_FAIL
   memset(&sc->s, 0, sizeof(sc->s));
   sc->s.lanes_per_row = lanes; sc->s.row_thresh = row_thresh; sc->s.nblk = (int32_t)nblk; sc->s.nseg = (int32_t)nseg;
   sc->s.nlong = (int32_t)nlong; sc->s.nhuge = (int32_t)nhuge; sc->s.npartial = (int32_t)npartial; sc->s.seg_mode = seg_mode;
@@ -210,6 +234,30 @@ int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched**
   sc->s.seg_e1 = (const int32_t*)sc->seg_e1.p; sc->s.seg_slot = (const int32_t*)sc->seg_slot.p; sc->s.long_row = (const int32_t*)sc->long_row.p;
   sc->s.long_slot = (const int32_t*)sc->long_slot.p;
   *out = sc;
+  return TGCN_OK;
+}
+
+int tgcn_sched_build(const tgcn_graph* g, int32_t C, int aligned16, tgcn_sched** out) {
+  if (!g) TGCN_FAIL(TGCN_ERR_INVALID, "sched_build: bad argument");
+  return tgcn_sched_build_csr(&g->csr, g->n_cols, C, aligned16, out);
+}
+
+/* The arrays of a library-built schedule copied (device to device, on `stream`) into arrays the caller owns, sized from the counts of
+ * tgcn_sched_get: blk_row [nblk+1], seg_* [max(nseg,1)], long_row [max(nlong,1)], long_slot [nlong+1, at least 2]. */
+int tgcn_sched_copy(const tgcn_sched* s, void* stream, int32_t* blk_row, int32_t* seg_row, int32_t* seg_e0, int32_t* seg_e1, int32_t* seg_slot,
+                    int32_t* long_row, int32_t* long_slot) {
+  if (!s || !blk_row || !seg_row || !seg_e0 || !seg_e1 || !seg_slot || !long_row || !long_slot) TGCN_FAIL(TGCN_ERR_INVALID, "sched_copy: null array");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t ns = (size_t)(s->s.nseg > 0 ? s->s.nseg : 1) * 4, nl = (size_t)(s->s.nlong > 0 ? s->s.nlong : 1) * 4;
+  const size_t nls = (size_t)(s->s.nlong > 0 ? s->s.nlong + 1 : 2) * 4;
+  if (hipMemcpyAsync(blk_row, s->blk_row.p, (size_t)(s->s.nblk + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(seg_row, s->seg_row.p, ns, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(seg_e0, s->seg_e0.p, ns, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(seg_e1, s->seg_e1.p, ns, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(seg_slot, s->seg_slot.p, ns, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(long_row, s->long_row.p, nl, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(long_slot, s->long_slot.p, nls, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    TGCN_FAIL(TGCN_ERR_LAUNCH, "sched_copy: copy failed");
   return TGCN_OK;
 }
 

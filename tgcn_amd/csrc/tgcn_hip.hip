@@ -9,7 +9,8 @@
 //   wgrad.h          dW_t = A_t^T G, two deterministic stages on the fp32 MFMA
 //   small_graph.h    graphs that fit in LDS: whole layer / basis in ONE launch (sparse, first-layer, dense matrix-pipe)
 //   pool_relayout.h  (Q,n,C) -> (n,Q,C), gcn_pool / gcn_pool_4, relu + pool pass
-//   graph_build.h    tgcn_graph_* / tgcn_sched_*: operand and schedule construction inside the library (host code, one-off)
+//   device_build.h   operand / schedule construction on the device: prefix sums, stable radix sort, CSR build, schedule kernels
+//   graph_build.h    tgcn_graph_* / tgcn_sched_* / tgcn_csr_build_f32: host-side orchestration of device_build.h (one-off per operand)
 // This file: the extern "C" entry points (argument checks, workspace carving, launches) declared in tgcn_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,6 +38,7 @@ namespace {
 #include "wgrad.h"
 #include "small_graph.h"
 #include "pool_relayout.h"
+#include "device_build.h"
 #include "graph_build.h"
 
 }  // namespace

@@ -22,6 +22,8 @@ DENSE_MAX_N = 256       # operands up to this size that store >= 1/4 of their en
 MAX_BLOCKS_HINT = 2048  # below this many blocks, make blocks smaller rather than leave CUs idle
 COMPACT_MIN_ROWS = 1 << 16     # operands at least this large ...
 COMPACT_MIN_EMPTY = 0.125      # ... with at least this share of structurally empty rows keep compact hop tensors (CompactPlan)
+BUILDER = "library"     # operands / schedules of device tensors: "library" = the HIP kernels of libtgcn_hip.so (csrc/device_build.h: own stable
+                        # radix sort, prefix sums, marks); "torch" = the torch index ops below (always for CPU tensors; the cross-check)
 BLOCK_ROWS_MAX = None   # cost of a row block at most this many entry-equivalents per lane group (None: 64 for rows up to 64 floats, else 256)
 
 
@@ -38,7 +40,13 @@ def _check_range(row, col, n, ncol):
 class Schedule:
     """Work schedule for one lane-group width (include/tgcn_hip.h: tgcn_csr_sched)."""
 
-    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None, seg_mode=None):
+    def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None, seg_mode=None, n_cols=None, builder=None):
+        defaults = (row_thresh is None and seg_len is None and seg_mode is None and ROW_THRESH == 32 and SEG_LEN == 32 and SEG_MODE == 0
+                    and SEG_KEY == "first" and BLOCK_ROWS_MAX is None and ROW_COST == 4 and HUGE_SLOTS == 64 and MAX_BLOCKS_HINT == 2048)
+        builder = BUILDER if builder is None else builder
+        if builder == "library" and rowptr.is_cuda and edges is not None and defaults:
+            self._build_library(rowptr, n, lanes_per_row, edges, n if n_cols is None else n_cols)
+            return
         row_thresh = ROW_THRESH if row_thresh is None else row_thresh
         seg_len = max(SEG_LEN if seg_len is None else seg_len, 1)
         seg_mode = (SEG_MODE if seg_mode is None else seg_mode) if lanes_per_row < 64 else 0
@@ -114,6 +122,41 @@ class Schedule:
                                        self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
                                        self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
                                        self.long_slot.data_ptr())
+
+
+def _sched_build_library(self, rowptr, n, lanes_per_row, edges, n_cols):
+    """Schedule through tgcn_sched_build_csr (device kernels of the library), copied into torch-owned arrays"""
+    import ctypes as C
+    L = _lib.lib()
+    nnz = int(rowptr[-1].item())
+    csr = _lib.CsrStruct(int(n), nnz, rowptr.data_ptr(), edges.data_ptr(), None)
+    # any row length with the right lane-group width: lanes -> a C that maps back to it (aligned rows of 4 floats per lane)
+    C_row = lanes_per_row * 4 if lanes_per_row < 64 else 256
+    assert L.tgcn_hop_lanes_per_row(C_row, 1) == lanes_per_row, (C_row, lanes_per_row)
+    h = C.c_void_p()
+    with torch.cuda.device(rowptr.device):
+        torch.cuda.current_stream().synchronize()            # the library builds on the default stream
+        _lib.check(L.tgcn_sched_build_csr(C.byref(csr), int(n_cols), C_row, 1, C.byref(h)))
+        try:
+            st = L.tgcn_sched_get(h).contents
+            dev = rowptr.device
+            i32 = lambda k: torch.empty(max(int(k), 1), dtype=torch.int32, device=dev)
+            self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial = st.nblk, st.nseg, st.nlong, st.nhuge, st.npartial
+            self.blk_row = i32(st.nblk + 1)
+            self.seg_row, self.seg_e0, self.seg_e1, self.seg_slot = i32(st.nseg), i32(st.nseg), i32(st.nseg), i32(st.nseg)
+            self.long_row = i32(st.nlong)
+            self.long_slot = torch.zeros(max(st.nlong + 1, 2), dtype=torch.int32, device=dev)
+            _lib.check(L.tgcn_sched_copy(h, _lib.stream_ptr(), _lib.ptr(self.blk_row), _lib.ptr(self.seg_row), _lib.ptr(self.seg_e0),
+                                         _lib.ptr(self.seg_e1), _lib.ptr(self.seg_slot), _lib.ptr(self.long_row), _lib.ptr(self.long_slot)))
+            self.lanes_per_row, self.row_thresh, self.seg_len, self.seg_mode = st.lanes_per_row, st.row_thresh, 32, st.seg_mode
+        finally:
+            L.tgcn_sched_destroy(h)
+    self.struct = _lib.SchedStruct(self.lanes_per_row, self.row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, self.seg_mode,
+                                   self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(), self.seg_e1.data_ptr(),
+                                   self.seg_slot.data_ptr(), self.long_row.data_ptr(), self.long_slot.data_ptr())
+
+
+Schedule._build_library = _sched_build_library
 
 
 class CompactPlan:
@@ -248,15 +291,33 @@ class GraphOperand:
         row = row.to(device=device, dtype=torch.int64)
         col = col.to(device=device, dtype=torch.int64)
         val = val.to(device=device, dtype=torch.float32)
-        _check_range(row, col, n, n if n_cols is None else n_cols)
+        if not (BUILDER == "library" and device.type == "cuda"):         # the library's builder checks the range itself
+            _check_range(row, col, n, n if n_cols is None else n_cols)
         if not (row.numel() == col.numel() == val.numel()):
             raise _lib.TgcnError("graph operand: row / col / val lengths differ")
+        if BUILDER == "library" and device.type == "cuda":
+            return GraphOperand._from_coo_library(n, row.contiguous(), col.contiguous(), val.contiguous(), device, n if n_cols is None else n_cols)
         # stable: duplicates of one (row, col) keep their given order, so two operands built from the same list sum them alike
         order = torch.argsort(row * (n if n_cols is None else max(n, n_cols)) + col, stable=True)
         counts = torch.bincount(row, minlength=n)
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
         torch.cumsum(counts, 0, out=rowptr[1:])
         return GraphOperand(n, _as_i32(rowptr), _as_i32(col[order]), val[order].contiguous(), n_cols)
+
+    @staticmethod
+    def _from_coo_library(n, row, col, val, device, n_cols):
+        """COO -> CSR by the HIP kernels of the library (tgcn_csr_build_f32: two stable radix sorts + a prefix sum) into torch-owned arrays"""
+        L = _lib.lib()
+        nnz = int(row.numel())
+        if nnz >= 2 ** 31 - 1 or n >= 2 ** 31 - 1 or n_cols >= 2 ** 31 - 1:
+            raise _lib.TgcnError("graph operand outside the int32 index range (n=%d nnz=%d)" % (n, nnz))
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=device)
+        edges = torch.empty((max(nnz, 1), 2), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            ws = torch.empty(L.tgcn_csr_build_workspace_bytes(n, nnz), dtype=torch.uint8, device=device)
+            _lib.check(L.tgcn_csr_build_f32(_lib.stream_ptr(), n, n_cols, nnz, _lib.ptr(row), _lib.ptr(col), _lib.ptr(val), _lib.ptr(rowptr),
+                                            _lib.ptr(edges), _lib.ptr(ws), ws.numel()))
+        return GraphOperand._from_packed(n, rowptr, edges, nnz, n_cols)
 
     @staticmethod
     def from_dense(L, device=None):
@@ -363,7 +424,7 @@ class GraphOperand:
         with self._lock:                  # replicas of one module may share an operand (nn.DataParallel threads)
             s = self._sched.get(lanes_per_row)
             if s is None:
-                s = self._sched[lanes_per_row] = Schedule(self.rowptr, self.n, lanes_per_row, edges=self.edges)
+                s = self._sched[lanes_per_row] = Schedule(self.rowptr, self.n, lanes_per_row, edges=self.edges, n_cols=self.n_cols)
         return s
 
     def schedule_for(self, C_row, aligned16=True):

@@ -74,7 +74,7 @@ def main():
         print("compact: %d rows with entries, %d empty" % (plan.n_c, plan.n_empty), flush=True)
         op = plan.rest
     lanes = _lib.lib().tgcn_hop_lanes_per_row(args.C // args.split, 1)
-    scheds = {m: graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, seg_mode=m) for m in sorted(set(int(m) for m in args.seg_modes.split(",")))}
+    scheds = {m: graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, seg_mode=m, n_cols=op.n_cols) for m in sorted(set(int(m) for m in args.seg_modes.split(",")))}
     for m, sm in scheds.items():
         print("seg_mode %d: blocks=%d segments=%d long rows=%d huge=%d partial slots=%d seg_len=%d" % (m, sm.nblk, sm.nseg, sm.nlong, sm.nhuge, sm.npartial, sm.seg_len), flush=True)
     s = op.schedule_for(args.C // args.split)
