@@ -158,6 +158,8 @@ int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* coun
  *   "hop_variant"     0 shipped hop kernel; 1.. alternative unroll / row-interleave shapes of hop.h
  *   "hop_xcd_remap"   1 (default): each XCD gets a contiguous range of row blocks; 0: row blocks round robin over the XCDs
  *   "hop_seg_remap"   1: each XCD gets a contiguous range of the column-ordered segment blocks; 0 (default): round robin
+ *   "hop_stream"      1 (default): outputs larger than the Infinity Cache (256 MB) take the form with non-temporal entry loads, row
+ *                     stores and partial-row stores (16-lane groups); 0: plain accesses always
  *   "hop_lds_pad"     bytes of unused dynamic LDS per hop_kernel workgroup: limits the workgroups per CU to 160 KB / pad (0: none)
  *   "project_variant" 0 auto; 1 exact-fp32 streaming-W; 2 exact-fp32 W-resident with 16-row wave tiles; 3 bf16x3 always;
  *                     4 exact-fp32 auto; 5 vector-ALU narrow kernel wherever it applies

@@ -227,3 +227,39 @@ def test_wide_bf16x3_projection_tail_tiles(M, gpu_device):
         _lib.check(L.tgcn_set_tuning(b"project_variant", 0))
     assert torch.equal(outs[0], outs[1])
     assert rel_err(outs[0].cpu().numpy(), ref) <= TOL
+
+
+def test_hop_streaming_form_keeps_the_result(gpu_device):
+    """Outputs larger than the Infinity Cache take hop_kernel's form with non-temporal entry loads, row stores and partial-row
+    stores (tgcn_set_tuning("hop_stream")): cache hints only -- bitwise the result of the plain form, long rows and fix-up included."""
+    from tgcn_amd import functional as F, graph, _lib
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n, m, C = 1_200_000, 8_000_000, 64
+    assert n * C * 4 > 256 << 20
+    row = torch.randint(0, n, (m,), device="cuda", generator=g)
+    col = (torch.rand(m, device="cuda", generator=g) ** 3 * n).long().clamp_(max=n - 1)
+    row[: 200_000] = torch.randint(0, 40, (200_000,), device="cuda", generator=g)          # long rows: segments + partial rows + fix-up
+    val = torch.randn(m, device="cuda", generator=g) * 0.1
+    op = graph.GraphOperand.from_coo(n, row, col, val)
+    s = op.schedule_for(C)
+    assert s.nlong > 0 and s.npartial > 0
+    x = torch.randn(1, n, C, device="cuda", generator=g)
+    z = torch.randn(1, n, C, device="cuda", generator=g)
+    L = _lib.lib()
+    outs = []
+    for on in (1, 0):
+        _lib.check(L.tgcn_set_tuning(b"hop_stream", on))
+        try:
+            outs.append(F.csr_hop(op, x, z=z, alpha=2.0, beta=-1.0, want_p=True))
+        finally:
+            _lib.check(L.tgcn_set_tuning(b"hop_stream", 1))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # and the plain form is the oracle-checked one: spot-check 2000 rows against a float64 row-by-row sum
+    rows = torch.randint(0, n, (2000,), device="cuda", generator=g).tolist() + list(range(40))
+    rp, e = op.rowptr.cpu().numpy(), op.edges.cpu().numpy()
+    xc = x[0].cpu().numpy().astype(np.float64)
+    got = outs[0][1][0].cpu().numpy()
+    for r in rows[:300] + rows[-40:]:
+        cols, vals = e[rp[r]: rp[r + 1], 0], e[rp[r]: rp[r + 1], 1].copy().view(np.float32).astype(np.float64)
+        ref = (vals[:, None] * xc[cols]).sum(0)
+        assert np.abs(got[r] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)

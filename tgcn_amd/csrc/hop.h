@@ -25,6 +25,7 @@ struct HopParams {
   float alpha, beta, gamma;
   int32_t nblk, nseg, nlong, nhuge, row_thresh;
   int32_t C, nb, nchunks, cpad, remap;
+  int32_t stream_out;            // the output tensor is larger than the Infinity Cache: entries, results and partial rows with non-temporal hints
   int32_t seg_mode, seg_remap;   // seg_mode 1: one WAVE per segment (tgcn_csr_sched.seg_mode); seg_remap: XCD-contiguous segment ranges
 };
 
@@ -68,7 +69,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // Tuning bits of the hop kernel (NTM): which accesses carry the non-temporal hint, and ev prefetch.
-constexpr int kNtEdges = 1, kNtStores = 2;
+constexpr int kNtEdges = 1, kNtStores = 2, kNtPartials = 4;
 
 template <int VEC>
 __device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[VEC]) {
@@ -289,7 +290,9 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
       if (slot < 0) {
         if (cact) finish_row<VEC, NTM>(p, b, p.seg_row[s], c0, acc[rr]);
       } else {
-        store_vec<VEC>(p.partial + ((int64_t)slot * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC, acc[rr]);
+        float* dst = p.partial + ((int64_t)slot * p.nb + b) * p.cpad + (chunk * LPR + t) * VEC;
+        if constexpr (NTM & kNtPartials) store_vec_nt<VEC>(dst, acc[rr]);
+        else store_vec<VEC>(dst, acc[rr]);
       }
     }
   }
@@ -382,9 +385,10 @@ inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3
   const int v = g_hop_variant.load();
   if (lpr == 16) {
     switch (v) {
-      case 1: launch_hop<16, 4, 8, 1>(st, p, grid); return true;
-      case 2: launch_hop<16, 4, 4, 2>(st, p, grid); return true;
-      case 3: launch_hop<16, 4, 2, 1>(st, p, grid); return true;
+      case 1: launch_hop<16, 4, 4, 1>(st, p, grid); return true;
+      case 2: launch_hop<16, 4, 8, 1, kNtEdges>(st, p, grid); return true;
+      case 3: launch_hop<16, 4, 8, 1, kNtEdges | kNtStores>(st, p, grid); return true;
+      case 4: launch_hop<16, 4, 8, 1, 0>(st, p, grid); return true;
       default: return false;
     }
   }
@@ -411,6 +415,8 @@ inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3
 
 // rows interleaved per lane group: wide operands (a whole wave per row chunk) run 4 rows at once
 template <int L> struct HopRows { static constexpr int value = (L == 64) ? 4 : 1; };
+// gathers in flight per lane and row: 8 for 16-lane groups (cfg5 on the compacted operand: 3.840 -> 3.804 ms, four A/B runs), 4 otherwise
+template <int L> struct HopUnroll { static constexpr int value = (L == 16) ? 8 : 4; };
 
 template <int VEC>
 int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
@@ -421,7 +427,10 @@ int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 
         /* interleave rows only when the grid still fills the chip afterwards */            \
         if (HopRows<L>::value > 1 && (int64_t)p.nblk * grid.y >= 4096)                       \
           launch_hop<L, VEC, 4, HopRows<L>::value>(st, p, grid);                            \
-        else launch_hop<L, VEC, 4, 1>(st, p, grid);                                         \
+        else if (L == 16 && VEC == 4 && p.stream_out)                                       \
+          /* once-read entries and once-written rows keep out of the L2 that holds the hub rows of X (cfg5: 3.79 -> 3.70 ms) */ \
+          launch_hop<L, VEC, HopUnroll<L>::value, 1, kNtEdges | kNtStores | kNtPartials>(st, p, grid); \
+        else launch_hop<L, VEC, HopUnroll<L>::value, 1>(st, p, grid);                       \
       } }                                                                                   \
     if (p.nlong > 0) { ProfScope ps(TGCN_PROF_HOP_FIXUP, st);                               \
       hipLaunchKernelGGL((hop_fixup_kernel<L, VEC>), fix_grid, dim3(kBlock), 0, st, p); }   \
