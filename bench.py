@@ -358,6 +358,7 @@ def main():
     ap.add_argument("--no-small-path", action="store_true", help="developer: disable the one-launch small-graph kernel")
     ap.add_argument("--compact-q-chunk", type=int, default=None, help="developer: time steps per pass of the compacted forward")
     ap.add_argument("--no-compact", action="store_true", help="developer: hop tensors for all vertices even when many rows are empty")
+    ap.add_argument("--tune", action="append", default=[], help="developer: key=value for tgcn_set_tuning (repeatable)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1, time sharding: skip the vertex-sharded / hybrid runs reported in `other_shardings`")
     ap.add_argument("--rehearsal-cpu", action="store_true", help="tests only: run the N > 1 control flow on the CPU with the gloo backend and scipy stand-ins for the HIP calls; nothing measured in this mode is a result")
     ap.add_argument("--extras-budget", type=float, default=150.0, help="seconds after which the extra runs are abandoned and the headline line is printed without them")
@@ -391,6 +392,9 @@ def main():
         _F.COMPACT = False
     if args.project_variant is not None:
         _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", args.project_variant))
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().tgcn_set_tuning(k.encode(), int(v)))
     op, spec = build_workload(args.workload, args.labeling, device, args.vertices, args.entries)
     q_total = spec["q"]
     strong_time = world > 1 and args.shard == "time" and args.scaling == "strong" and spec["q"] >= world
