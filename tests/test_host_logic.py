@@ -260,3 +260,79 @@ def test_operand_cache_is_thread_safe():
     [t.join() for t in ts]
     assert len(built) == 2
     assert all(got[i] is got[i % 2] for i in range(8))
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_compact_plan_arrays(symmetric, monkeypatch):
+    """graph.CompactPlan on CPU tensors: the non-empty rows in order, both operands over the same rows and entry order, columns of
+    `rest` in compact ids with entries into empty rows pointing at the zero row -- so that rest @ P (P: compact rows + a zero row)
+    equals the rows of L @ P_full for every P_full that is zero on the empty rows (what hop tensors are for k >= 1)."""
+    from tgcn_amd import graph
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    rng = np.random.default_rng(7)
+    n = 500
+    keep = rng.random(n) < 0.5
+    src = rng.integers(0, n, 4000)
+    dst = rng.integers(0, n, 4000)
+    if symmetric:
+        ok = keep[src] & keep[dst]
+        row, col = np.concatenate([src[ok], dst[ok]]), np.concatenate([dst[ok], src[ok]])
+    else:
+        ok = keep[src]
+        row, col = src[ok], dst[ok]                 # columns may be vertices without entries of their own
+    val = rng.standard_normal(row.shape[0]).astype(np.float32)
+    op = graph.GraphOperand.from_coo(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val))
+    plan = op.compact_plan()
+    deg = np.bincount(row, minlength=n)
+    assert plan is not None and op.compact_plan() is plan           # built once
+    rows, empty = plan.rows.numpy(), plan.empty.numpy()
+    assert np.array_equal(rows, np.flatnonzero(deg > 0)) and np.array_equal(empty, np.flatnonzero(deg == 0))
+    assert plan.n_c == len(rows) and plan.n_empty == len(empty) and plan.first.n == plan.rest.n == plan.n_c
+    assert plan.first.n_cols == n and plan.rest.n_cols == plan.n_c + 1 and plan.first.nnz == plan.rest.nnz == op.nnz
+    assert plan.first.edges.data_ptr() == op.edges.data_ptr()       # hop 1 shares the operand's entry array
+    assert torch.equal(plan.first.rowptr, plan.rest.rowptr) and plan.first._sched is plan.rest._sched
+    L = op.to_scipy().astype(np.float64)
+    P_full = rng.standard_normal((n, 3))
+    P_full[empty] = 0
+    cid = np.full(n, plan.n_c)
+    cid[rows] = np.arange(plan.n_c)
+    e = plan.rest.edges.numpy()[: op.nnz]
+    assert np.array_equal(e[:, 0], cid[op.edges.numpy()[: op.nnz, 0]])
+    if not symmetric:
+        assert (e[:, 0] == plan.n_c).any()
+    import scipy.sparse as sp
+    rp = plan.rest.rowptr.numpy()
+    rest = sp.csr_matrix((e[:, 1].copy().view(np.float32).astype(np.float64), e[:, 0], rp), shape=(plan.n_c, plan.n_c + 1))
+    P_c = np.concatenate([P_full[rows], np.zeros((1, 3))])
+    assert np.allclose(rest @ P_c, (L @ P_full)[rows])
+    first = sp.csr_matrix((e[:, 1].copy().view(np.float32).astype(np.float64), op.edges.numpy()[: op.nnz, 0], rp), shape=(plan.n_c, n))
+    x = rng.standard_normal((n, 3))
+    assert np.allclose(first @ x, (L @ x)[rows])
+    # operands without (enough) empty rows, or below the size threshold, decline
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1 << 16)
+    op2 = graph.GraphOperand.from_coo(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val))
+    assert op2.compact_plan() is None
+
+
+@pytest.mark.parametrize("lpr", [4, 16])
+def test_wave_segment_schedule_shapes(lpr, monkeypatch):
+    """seg_mode 1 (one wave per segment): segments of 32 * (64 / lanes) entries, rows up to that length are whole-row segments"""
+    from tgcn_amd import graph
+    monkeypatch.setattr(graph, "SEG_MODE", 1)
+    rng = np.random.default_rng(lpr)
+    n = 2000
+    wave_len = 32 * (64 // lpr)
+    row, col, val = _rand_csr(n, 9000, rng, hubs=((3, wave_len), (77, wave_len + 1), (500, 5 * wave_len + 3), (1999, 33)))
+    op = graph.GraphOperand.from_coo(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val))
+    s = op.schedule(lpr)
+    assert s.seg_mode == 1 and s.seg_len == wave_len and s.struct.seg_mode == 1
+    rowptr = op.rowptr.numpy().astype(np.int64)
+    deg = np.diff(rowptr)
+    seg_row, e0, e1, slot = (t.numpy()[: s.nseg] for t in (s.seg_row, s.seg_e0, s.seg_e1, s.seg_slot))
+    assert np.all(e1 - e0 <= wave_len)
+    for r in np.flatnonzero(deg > s.row_thresh):
+        mine = np.flatnonzero(seg_row == r)
+        assert len(mine) == -(-deg[r] // wave_len)
+        assert (slot[mine] < 0).all() == (deg[r] <= wave_len)
+    assert s.nlong == int((deg > wave_len).sum())
+    assert graph.Schedule(op.rowptr, n, 64, edges=op.edges).seg_mode == 0      # a whole wave per row chunk: nothing to fold
