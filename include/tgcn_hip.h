@@ -264,7 +264,9 @@ int tgcn_cheb_forward_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched*
  * have entries only (compact ids = rank among them):
  *   A_first  n_c rows, columns in the caller's labels (hop 1 gathers from x);  A_rest  the same rows and entry order with
  *            columns in compact ids, entries whose column is an empty vertex pointing at the zero row n_c  (hops 2..K-1);
- *   rows[n_c] / empty_rows[n_empty]  caller's label of every compact / empty row, ascending;  sched: shared by both operands.
+ *   rows[n_c] / empty_rows[n_empty]  caller's label of every compact / empty row, ascending;  sched: shared by both operands;
+ *   compact_id[n] (nullable)  compact id of every vertex, n_c for the empty ones: lets the projection run as ONE launch over all
+ *            vertices in order (tgcn_set_tuning("compact_proj", 1)) instead of one launch per row class.
  * The projection reads x, bias and writes out through the row maps; hop tensors, hop writes and four of the five projection
  * terms shrink by n_empty / n.  Bitwise equal to tgcn_cheb_forward_f32 (layout 0) on the same operand.  K >= 2. */
 size_t tgcn_cheb_forward_compact_workspace_bytes(const tgcn_csr_sched* sched, int32_t K, int64_t q, int64_t n_c, int32_t C,
@@ -272,7 +274,7 @@ size_t tgcn_cheb_forward_compact_workspace_bytes(const tgcn_csr_sched* sched, in
 int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const tgcn_csr* A_rest, const tgcn_csr_sched* sched,
                                   int32_t K, int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
                                   const float* bias, int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows,
-                                  int64_t n_empty, int64_t q_chunk, void* workspace, size_t workspace_bytes);
+                                  int64_t n_empty, const int32_t* compact_id, int64_t q_chunk, void* workspace, size_t workspace_bytes);
 
 /* "Project first" form of the same layer for wide inputs and narrow outputs (N well below C = H*f, e.g.
  * TGCNCheb_H(L, 1, 32, K, 1200)): Z = x . Wcat for all K terms in ONE projection (Wcat: C x (K*N), column block j =

@@ -111,9 +111,13 @@ def test_compact_forward_equals_plain_forward(q, C, N, K, bias_kind, symmetric, 
         plain = F.cheb_forward_raw(op, x, W2, bias, bias_kind, F.MODE_POWER, K, layout=0, q_chunk=1)
         comp = F.cheb_forward_compact(plan, x, W2, bias, bias_kind, K, q_chunk=1)
         comp2 = F.cheb_forward_compact(plan, x, W2, bias, bias_kind, K, q_chunk=2)
+        _lib.check(_lib.lib().tgcn_set_tuning(b"compact_proj", 1))      # ONE projection over all vertices, hop tensors through the id map
+        comp3 = F.cheb_forward_compact(plan, x, W2, bias, bias_kind, K, q_chunk=2)
     finally:
         _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 0))
-    assert torch.equal(plain, comp) and torch.equal(comp, comp2)
+        _lib.check(_lib.lib().tgcn_set_tuning(b"compact_proj", 0))
+    assert torch.equal(plain, comp) and torch.equal(comp, comp2) and torch.equal(comp, comp3)
+    assert np.array_equal(plan.cid.cpu().numpy()[plan.rows.cpu().numpy()], np.arange(plan.n_c)) and (plan.cid[plan.empty.long()] == plan.n_c).all()
     # default kernels, through the dispatcher, against the C restatement of the reference's algorithm (unfolded weights)
     out = F.layer_forward(op, x, W, F.power_fold_matrix(K, x.device) if K > 2 else None, bias, bias_kind, F.MODE_POWER)
     rowptr = op.rowptr.cpu().numpy()

@@ -89,7 +89,7 @@ SIGNATURES = {
     "tgcn_cheb_forward_compact_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64]),
     "tgcn_cheb_forward_compact_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32,
                                                 C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P,
-                                                C.c_int64, C.c_int64, _P, C.c_size_t]),
+                                                C.c_int64, _P, C.c_int64, _P, C.c_size_t]),
     "tgcn_cheb_forward_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_basis_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_forward_small_pool_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),

@@ -19,7 +19,9 @@ struct ProjParams {
   int32_t win_n, win_t;   // > 0: row m of A_t is the window starting at A_t[(m / win_n) * win_t + (m % win_n)]
   // Row map (compacted operands: the hop tensors hold only the vertices that have stored entries): tile row m is the
   // caller's vertex rowmap[m] -- its output row, its bias row, and its row in every term whose bit is set in `mapped`
-  // (term 0 = x in the caller's labels); the other terms are read at row m.
+  // (term 0 = x in the caller's labels); the other terms are read at row m.  With bit 31 of `mapped` set (kProjMapTermsOnly) the
+  // map applies to the flagged terms ONLY: output and bias rows are the tile rows themselves (tiles over all vertices in order, the
+  // compact hop tensors read through the vertex -> compact id map, empty vertices pointing at the zero row).
   const int32_t* rowmap;
   uint32_t mapped;
   // Batch of samples sharing the tile rows (project_x3_kernel<NT, true> only; the host loops for the other kernels): sample b
@@ -76,13 +78,15 @@ __device__ __forceinline__ void pooled_store(const ProjParams& p, const float* m
   }
 }
 
+constexpr uint32_t kProjMapTermsOnly = 0x80000000u;
+
 // row of term `term` that tile row m reads
 __device__ __forceinline__ int64_t proj_arow(const ProjParams& p, int term, int64_t m) {
   return (p.rowmap && ((p.mapped >> term) & 1u)) ? (int64_t)p.rowmap[m] : m;
 }
 // output row of tile row m: the row map, or the layout-1 interleave (vertex-major tile rows -> sample-major output)
 __device__ __forceinline__ int64_t proj_orow(const ProjParams& p, int64_t m) {
-  if (p.rowmap) return (int64_t)p.rowmap[m];
+  if (p.rowmap && !(p.mapped & kProjMapTermsOnly)) return (int64_t)p.rowmap[m];
   return (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
 }
 

@@ -61,6 +61,7 @@ int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "small_dense") == 0) { g_small_dense.store(value); return TGCN_OK; }
   if (key && strcmp(key, "small_narrow") == 0) { g_small_narrow.store(value); return TGCN_OK; }
   if (key && strcmp(key, "x3_form") == 0) { g_x3_form.store(value); return TGCN_OK; }
+  if (key && strcmp(key, "compact_proj") == 0) { g_compact_proj.store(value); return TGCN_OK; }
   if (key && strcmp(key, "x3_tail") == 0) { g_x3_tail.store(value != 0); return TGCN_OK; }
   if (key && strcmp(key, "overlap") == 0) { g_overlap.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
@@ -764,7 +765,7 @@ size_t tgcn_cheb_forward_compact_workspace_bytes(const tgcn_csr_sched* S, int32_
 int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const tgcn_csr* A_rest, const tgcn_csr_sched* S, int32_t K,
                                   int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W, const float* bias,
                                   int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows, int64_t n_empty,
-                                  int64_t q_chunk, void* workspace, size_t workspace_bytes) {
+                                  const int32_t* compact_id, int64_t q_chunk, void* workspace, size_t workspace_bytes) {
   if (!A_first || !A_rest || !S || !x || !W || !out || !rows) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: null operand");
   const int64_t n_c = A_first->n;
   if (K < 2 || K > kMaxTerms || q < 1 || n < 1 || C < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: bad shape (K=%d)", K);
@@ -782,8 +783,9 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
   const int64_t bs_c = (n_c + 1) * (int64_t)C;            // sample stride of a compact hop tensor
   auto hop_ptr = [&](int k) { return (float*)(ws + (size_t)(k - 1) * hop_bytes); };
   hipStream_t st = (hipStream_t)stream;
-  // the zero row of the tensors that are gathered from (hops 1 .. K-2); no hop writes it, so once per call
-  for (int k = 1; k + 1 < K; ++k)
+  // the zero row of every hop tensor (gathered from by the next hop and, with compact_id, by the projection for the empty
+  // vertices); no hop writes it, so once per call
+  for (int k = 1; k < K; ++k)
     if (hipMemset2DAsync(hop_ptr(k) + n_c * (int64_t)C, (size_t)bs_c * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)qc, st) != hipSuccess)
       TGCN_FAIL(TGCN_ERR_LAUNCH, "forward_compact: memset failed");
   const float* terms[kMaxTerms];
@@ -808,6 +810,15 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
     terms[0] = x0;
     for (int k = 1; k < K; ++k) terms[k] = hop_ptr(k);
     float* o = out + q0 * n * N;
+    if (compact_id && g_compact_proj.load() == 1) {
+      // ONE launch over all vertices in order: x, bias and out stream contiguously; terms 1..K-1 are read through the vertex ->
+      // compact id map (empty vertices read the zero row): twice the tile work of the split form, every byte in whole DRAM pages
+      uint32_t bits = kProjMapTermsOnly;
+      for (int k = 1; k < K; ++k) bits |= (1u << k);
+      rc = project_impl(stream, n, C, N, K, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, compact_id, bits, (int32_t)qn, a_bs, n * (int64_t)N);
+      if (rc != TGCN_OK) return rc;
+      continue;
+    }
     // vertices with stored entries: all K terms (x through the row map, hop tensors in compact rows)
     rc = project_impl(stream, n_c, C, N, K, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, rows, 1u, (int32_t)qn, a_bs, n * (int64_t)N);
     if (rc != TGCN_OK) return rc;

@@ -264,7 +264,7 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
     _lib.check(L.tgcn_cheb_forward_compact_f32(_lib.stream_ptr(), C.byref(plan.first.struct), C.byref(plan.rest.struct),
                                                C.byref(sched.struct), K, q, n, Crow, N, _lib.ptr(x3), _lib.ptr(Wt), _lib.ptr(bias),
                                                bias_kind, _lib.ptr(out), _lib.ptr(plan.rows), _lib.ptr(plan.empty), plan.n_empty,
-                                               q_chunk, _lib.ptr(ws), ws.numel()))
+                                               _lib.ptr(plan.cid), q_chunk, _lib.ptr(ws), ws.numel()))
     return out
 
 

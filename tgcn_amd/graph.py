@@ -181,7 +181,7 @@ class CompactPlan:
         edges_c = op.edges.clone()
         if op.nnz:
             edges_c[:, 0] = cid[op.edges[:, 0].long()]
-        del cid
+        self.cid = cid                              # compact id of every vertex, n_c for the empty ones
         self.first = GraphOperand._from_packed(self.n_c, rowptr_c, op.edges, op.nnz, n_cols=op.n)
         self.rest = GraphOperand._from_packed(self.n_c, rowptr_c, edges_c, op.nnz, n_cols=self.n_c + 1)
         self.first._sched = self.rest._sched       # one schedule: built from `rest`, valid for both
