@@ -916,7 +916,8 @@ def test_from_dense_keeps_only_stored_entries_documented_deviation(gpu_device):
     assert np.abs(out[fin] - ref[fin]).max() <= 1e-5 * np.abs(ref[fin]).max()
 
 
-@pytest.mark.parametrize("key,value", [("hop_xcd_remap", 0), ("hop_lds_pad", 40 * 1024), ("hop_lds_pad", 80 * 1024), ("hop_seg_remap", 1)])
+@pytest.mark.parametrize("key,value", [("hop_xcd_remap", 0), ("hop_lds_pad", 40 * 1024), ("hop_lds_pad", 80 * 1024), ("hop_seg_remap", 1),
+                                       ("hop_mix", 1), ("hop_mix", 2), ("hop_stream", 0)])
 def test_hop_scheduling_switches_keep_the_result(key, value, gpu_device):
     """hop_xcd_remap / hop_lds_pad change where and how many workgroups run, never what they compute: bitwise the same hop"""
     from tgcn_amd import functional as F, _lib
@@ -932,4 +933,4 @@ def test_hop_scheduling_switches_keep_the_result(key, value, gpu_device):
     try:
         assert torch.equal(F.csr_hop(op, x), base)
     finally:
-        _lib.check(_lib.lib().tgcn_set_tuning(key.encode(), {"hop_xcd_remap": 1, "hop_lds_pad": 0, "hop_seg_remap": 0}[key]))
+        _lib.check(_lib.lib().tgcn_set_tuning(key.encode(), {"hop_xcd_remap": 1, "hop_lds_pad": 0, "hop_seg_remap": 0, "hop_mix": 0, "hop_stream": 1}[key]))

@@ -57,6 +57,7 @@ inline void allow_large_lds(const void* fn, int bytes) {
 std::atomic<int> g_hop_variant{0};
 std::atomic<int> g_hop_remap{1};        // hop_kernel: row blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)
 std::atomic<int> g_hop_seg_remap{0};    // hop_kernel: segment blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)
+std::atomic<int> g_hop_mix{0};          // hop_kernel: row blocks dealt evenly among the segment blocks (1) or all in front (0)
 std::atomic<int> g_hop_stream{1};       // hop_kernel: non-temporal entries / stores / partial rows when the output exceeds the Infinity Cache (0: never)
 std::atomic<int> g_hop_lds_pad{0};      // hop_kernel: bytes of unused dynamic LDS per workgroup (occupancy limiter, developer A/B)
 std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel

@@ -308,12 +308,15 @@ __global__ void edge_normalise_kernel(const int64_t* __restrict__ row, const int
 // --------------------------------------------------------------------------------------------------
 // cost[i] = (entries of row i if <= row_thresh else 0) + row_cost;  is_seg[i] = entries > row_thresh
 __global__ void sched_cost_kernel(const int32_t* __restrict__ rowptr, int64_t n, int row_thresh, int row_cost, int64_t* __restrict__ cost,
-                                  int64_t* __restrict__ is_seg) {
+                                  int64_t* __restrict__ is_seg, unsigned long long* __restrict__ n_empty) {
+  unsigned long long mine = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t d = rowptr[i + 1] - rowptr[i];
     cost[i] = (d > row_thresh ? 0 : d) + row_cost;
     is_seg[i] = d > row_thresh ? 1 : 0;
+    mine += (d == 0);
   }
+  if (mine) atomicAdd(n_empty, mine);      // integer count: order-independent
 }
 
 // blk_row[b] = min(searchsorted(cum, b * target) + 1, n) for 1 <= b < nblk (cum = inclusive prefix sum of the costs); ends 0 and n

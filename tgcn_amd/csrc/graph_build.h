@@ -169,15 +169,17 @@ int tgcn_sched_build_csr(const tgcn_csr* A, int64_t n_cols, int32_t C, int align
   if (!sc) TGCN_FAIL(TGCN_ERR_LAUNCH, "sched_build: out of host memory");
 #define TGCN_SCHED_FAIL(...) do { delete sc; TGCN_FAIL(TGCN_ERR_LAUNCH, __VA_ARGS__); } while (0)
   // ---- short rows: nnz-balanced row blocks (cost = entries + 4 per row; rows cut into segments cost 4)
-  DeviceBuf cost, is_seg, pos, scanws;
-  if (cost.alloc((size_t)n * 8) || is_seg.alloc((size_t)(n + 1) * 8) || pos.alloc((size_t)(n + 1) * 8) || scanws.alloc(scan_ws_elems(n + 1) * 8) ||
+  DeviceBuf cost, is_seg, pos, scanws, empties;
+  if (empties.zero(8) || cost.alloc((size_t)n * 8) || is_seg.alloc((size_t)(n + 1) * 8) || pos.alloc((size_t)(n + 1) * 8) || scanws.alloc(scan_ws_elems(n + 1) * 8) ||
       hipMemset(is_seg.p, 0, (size_t)(n + 1) * 8) != hipSuccess)
     TGCN_SCHED_FAIL("sched_build: device allocation failed");
-  hipLaunchKernelGGL(sched_cost_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, st, A->rowptr, n, (int)row_thresh, (int)row_cost, (int64_t*)cost.p, (int64_t*)is_seg.p);
+  hipLaunchKernelGGL(sched_cost_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, st, A->rowptr, n, (int)row_thresh, (int)row_cost, (int64_t*)cost.p, (int64_t*)is_seg.p,
+                     (unsigned long long*)empties.p);
   scan_i64(st, (const int64_t*)cost.p, (int64_t*)cost.p, n, 1, (int64_t*)scanws.p);                   // cum = inclusive prefix sum
   scan_i64(st, (const int64_t*)is_seg.p, (int64_t*)pos.p, n + 1, 0, (int64_t*)scanws.p);              // pos[n] = rows cut into segments
-  int64_t total = 0, m = 0;
-  if (read_back(&total, (const int64_t*)cost.p + (n - 1)) || read_back(&m, (const int64_t*)pos.p + n)) TGCN_SCHED_FAIL("sched_build: device read failed");
+  int64_t total = 0, m = 0, n_empty = 0;
+  if (read_back(&total, (const int64_t*)cost.p + (n - 1)) || read_back(&m, (const int64_t*)pos.p + n) || read_back(&n_empty, (const int64_t*)empties.p))
+    TGCN_SCHED_FAIL("sched_build: device read failed");
   const int64_t cap = lanes <= 16 ? 64 : 256;        // narrow rows: small blocks keep an XCD's gather window inside its L2 (tgcn_amd/graph.py)
   const int64_t target = std::max<int64_t>(gpb * 16, std::min<int64_t>(gpb * cap, (total + max_blocks_hint - 1) / max_blocks_hint));
   const int64_t nblk = std::max<int64_t>(1, (total + target - 1) / target);
@@ -230,6 +232,7 @@ int tgcn_sched_build_csr(const tgcn_csr* A, int64_t n_cols, int32_t C, int align
   memset(&sc->s, 0, sizeof(sc->s));
   sc->s.lanes_per_row = lanes; sc->s.row_thresh = row_thresh; sc->s.nblk = (int32_t)nblk; sc->s.nseg = (int32_t)nseg;
   sc->s.nlong = (int32_t)nlong; sc->s.nhuge = (int32_t)nhuge; sc->s.npartial = (int32_t)npartial; sc->s.seg_mode = seg_mode;
+  sc->s.row_mix = (n_empty * 8 >= n) ? 1 : 0;            // many empty rows: their blocks among the segment blocks (tgcn_csr_sched.row_mix)
   sc->s.blk_row = (const int32_t*)sc->blk_row.p; sc->s.seg_row = (const int32_t*)sc->seg_row.p; sc->s.seg_e0 = (const int32_t*)sc->seg_e0.p;
   sc->s.seg_e1 = (const int32_t*)sc->seg_e1.p; sc->s.seg_slot = (const int32_t*)sc->seg_slot.p; sc->s.long_row = (const int32_t*)sc->long_row.p;
   sc->s.long_slot = (const int32_t*)sc->long_slot.p;

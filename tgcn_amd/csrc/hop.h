@@ -25,6 +25,7 @@ struct HopParams {
   float alpha, beta, gamma;
   int32_t nblk, nseg, nlong, nhuge, row_thresh;
   int32_t C, nb, nchunks, cpad, remap;
+  int32_t mix_period;            // > 1: one row block every mix_period block ids (0 / 1: all row blocks first)
   int32_t stream_out;            // the output tensor is larger than the Infinity Cache: entries, results and partial rows with non-temporal hints
   int32_t seg_mode, seg_remap;   // seg_mode 1: one WAVE per segment (tgcn_csr_sched.seg_mode); seg_remap: XCD-contiguous segment ranges
 };
@@ -212,6 +213,17 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
   const bool cact = c0 < p.C;
   const float* Xc = p.X + (int64_t)b * p.x_bs + (cact ? c0 : 0);
   int bid = blockIdx.x;
+  if (p.mix_period > 1) {
+    // row blocks dealt evenly among the segment blocks (one every mix_period ids) instead of all in front: the short rows wait on
+    // HBM, the segments are bound by the gather path into the CUs -- side by side on a CU they fill each other's gaps
+    const int q = bid / p.mix_period;
+    if (bid % p.mix_period == 0 && q < p.nblk) bid = q;                                              // row block q
+    else bid = p.nblk + (bid - min(p.nblk, (bid + p.mix_period - 1) / p.mix_period));                // segment block, in order
+  }
+  else if (p.mix_period < 0) {               // segment blocks first, row blocks behind them
+    const int nsb = (int)gridDim.x - p.nblk;
+    bid = bid < nsb ? p.nblk + bid : bid - nsb;
+  }
   if (bid < p.nblk) {
     if (p.remap) bid = xcd_remap(bid, p.nblk);
     const int r0 = p.blk_row[bid], r1 = p.blk_row[bid + 1];

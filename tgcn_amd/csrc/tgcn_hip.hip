@@ -55,6 +55,7 @@ int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "hop_xcd_remap") == 0) { g_hop_remap.store(value != 0); return TGCN_OK; }
   if (key && strcmp(key, "hop_seg_remap") == 0) { g_hop_seg_remap.store(value != 0); return TGCN_OK; }
+  if (key && strcmp(key, "hop_mix") == 0) { g_hop_mix.store(value); return TGCN_OK; }
   if (key && strcmp(key, "hop_stream") == 0) { g_hop_stream.store(value != 0); return TGCN_OK; }
   if (key && strcmp(key, "hop_lds_pad") == 0) { if (value < 0 || value > 160 * 1024) TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: hop_lds_pad %d", value); g_hop_lds_pad.store(value); return TGCN_OK; }
   if (key && strcmp(key, "project_variant") == 0) { g_proj_variant.store(value); return TGCN_OK; }
@@ -146,6 +147,12 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
   p.nblk = S->nblk; p.nseg = S->nseg; p.nlong = S->nlong; p.nhuge = S->nhuge; p.row_thresh = S->row_thresh;
   p.C = C; p.nb = nb; p.nchunks = g.nchunks; p.cpad = g.cpad; p.remap = g_hop_remap.load();
   p.seg_mode = S->seg_mode; p.seg_remap = g_hop_seg_remap.load();
+  {
+    const int seg_per_block = (S->seg_mode == 1 && g.lpr < 64) ? kBlock / 64 : kBlock / g.lpr;      // launch_hop's count (R = 1 where it matters)
+    const int64_t nsb = (S->nseg + seg_per_block - 1) / seg_per_block;
+    const int mix = g_hop_mix.load();
+    p.mix_period = ((mix == 1 || (mix == 0 && S->row_mix)) && S->nblk > 0 && nsb >= S->nblk && g.lpr < 64) ? (int32_t)((S->nblk + nsb) / S->nblk) : (mix == 2 && nsb > 0 ? -1 : 0);
+  }
   p.stream_out = ((int64_t)A->n * C * (int64_t)sizeof(float) * nb > ((int64_t)256 << 20)) && g_hop_stream.load();
   const int gpb = kBlock / g.lpr;
   const int seg_blocks = (S->nseg + gpb - 1) / gpb;

@@ -254,9 +254,12 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
         # for all its time steps, so take up to 4 while the K-1 compact hop tensors stay within a quarter of the free memory
         q_chunk = 1
         if bias_kind == BIAS_VERTEX_CHANNEL and q > 1:
-            free = torch.cuda.mem_get_info(x3.device)[0]
-            per_q = (K - 1) * (plan.n_c + 1) * Crow * 4
-            q_chunk = int(max(1, min(q, 4, (free // 4) // max(per_q, 1))))
+            key = (K, Crow, q)
+            q_chunk = plan.q_chunk_cache.get(key)
+            if q_chunk is None:            # asked once per shape: no host query on later forwards (nor under hipGraph capture)
+                free = torch.cuda.mem_get_info(x3.device)[0]
+                per_q = (K - 1) * (plan.n_c + 1) * Crow * 4
+                q_chunk = plan.q_chunk_cache[key] = int(max(1, min(q, 4, (free // 4) // max(per_q, 1))))
     sched = plan.schedule_for(Crow, Crow % 4 == 0)
     ws_bytes = L.tgcn_cheb_forward_compact_workspace_bytes(C.byref(sched.struct), K, q, plan.n_c, Crow, q_chunk)
     ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)

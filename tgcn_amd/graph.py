@@ -118,7 +118,9 @@ class Schedule:
         self.row_thresh = row_thresh
         self.seg_len = seg_len
         self.seg_mode = seg_mode
-        self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, seg_mode,
+        # >= 1/8 structurally empty rows: their row blocks (mostly streaming zero writes) are dealt among the segment blocks
+        self.row_mix = int(int((deg == 0).sum().item()) * 8 >= n)
+        self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, seg_mode, self.row_mix, 0,
                                        self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
                                        self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
                                        self.long_slot.data_ptr())
@@ -148,11 +150,11 @@ def _sched_build_library(self, rowptr, n, lanes_per_row, edges, n_cols):
             self.long_slot = torch.zeros(max(st.nlong + 1, 2), dtype=torch.int32, device=dev)
             _lib.check(L.tgcn_sched_copy(h, _lib.stream_ptr(), _lib.ptr(self.blk_row), _lib.ptr(self.seg_row), _lib.ptr(self.seg_e0),
                                          _lib.ptr(self.seg_e1), _lib.ptr(self.seg_slot), _lib.ptr(self.long_row), _lib.ptr(self.long_slot)))
-            self.lanes_per_row, self.row_thresh, self.seg_len, self.seg_mode = st.lanes_per_row, st.row_thresh, 32, st.seg_mode
+            self.lanes_per_row, self.row_thresh, self.seg_len, self.seg_mode, self.row_mix = st.lanes_per_row, st.row_thresh, 32, st.seg_mode, st.row_mix
         finally:
             L.tgcn_sched_destroy(h)
     self.struct = _lib.SchedStruct(self.lanes_per_row, self.row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, self.seg_mode,
-                                   self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(), self.seg_e1.data_ptr(),
+                                   self.row_mix, 0, self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(), self.seg_e1.data_ptr(),
                                    self.seg_slot.data_ptr(), self.long_row.data_ptr(), self.long_slot.data_ptr())
 
 
@@ -184,6 +186,7 @@ class CompactPlan:
         self.cid = cid                              # compact id of every vertex, n_c for the empty ones
         self.first = GraphOperand._from_packed(self.n_c, rowptr_c, op.edges, op.nnz, n_cols=op.n)
         self.rest = GraphOperand._from_packed(self.n_c, rowptr_c, edges_c, op.nnz, n_cols=self.n_c + 1)
+        self.q_chunk_cache = {}                     # functional.cheb_forward_compact: time steps per pass, chosen once per shape
         self.first._sched = self.rest._sched       # one schedule: built from `rest`, valid for both
         self.first._lock = self.rest._lock
 

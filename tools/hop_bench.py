@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--remap", default="1", help="comma list of hop_xcd_remap values, each crossed with the others")
     ap.add_argument("--seg-modes", default="1", help="comma list of tgcn_csr_sched.seg_mode values (0 lane-group segments, 1 wave segments)")
     ap.add_argument("--seg-remaps", default="0", help="comma list of hop_seg_remap values")
+    ap.add_argument("--mix", default="0", help="comma list of hop_mix values (row blocks dealt among the segment blocks)")
     ap.add_argument("--compact", action="store_true", help="time the hop on the compacted operand (graph.CompactPlan.rest: only rows with entries)")
     ap.add_argument("--drop-core", type=int, default=None, help="remove the entries whose row AND column are among the H vertices of largest degree (what a hub-core kernel would take over)")
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
@@ -82,8 +83,8 @@ def main():
     x = torch.randn(1, op.n_cols, args.C, device=dev)
     y = torch.empty(1, op.n, args.C, device=dev)
     ref = None
-    variants = [(int(v), int(pd), int(rm), int(sm), int(sr)) for v in args.variants.split(",") for pd in args.lds_pads.split(",") for rm in args.remap.split(",")
-                for sm in args.seg_modes.split(",") for sr in args.seg_remaps.split(",")]
+    variants = [(int(v), int(pd), int(rm), int(sm), int(sr), int(mx)) for v in args.variants.split(",") for pd in args.lds_pads.split(",") for rm in args.remap.split(",")
+                for sm in args.seg_modes.split(",") for sr in args.seg_remaps.split(",") for mx in args.mix.split(",")]
     times = {v: [] for v in variants}
     fix = {v: [] for v in variants}
     L = _lib.lib()
@@ -93,6 +94,7 @@ def main():
             _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", v[1] * 1024))
             _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", v[2]))
             _lib.check(L.tgcn_set_tuning(b"hop_seg_remap", v[4]))
+            _lib.check(L.tgcn_set_tuning(b"hop_mix", v[5]))
             op._sched[lanes] = scheds[v[3]]
             _lib.profile_start(16)
             cs = args.C // args.split
@@ -111,6 +113,7 @@ def main():
     _lib.check(L.tgcn_set_tuning(b"hop_lds_pad", 0))
     _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", 1))
     _lib.check(L.tgcn_set_tuning(b"hop_seg_remap", 0))
+    _lib.check(L.tgcn_set_tuning(b"hop_mix", 0))
     alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph in ('rmat', 'banded') else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
