@@ -112,6 +112,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 4      # include/tgcn_hip.h: TGCN_ABI_VERSION
 
 
 def source_hash():
@@ -148,6 +149,14 @@ def build(verbose=False, force=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    try:        # the stamp certifies a library that loads and speaks this ABI, not merely one that linked
+        probe = C.CDLL(tmp)
+        probe.tgcn_abi_version.restype = C.c_int
+        if probe.tgcn_abi_version() != ABI_VERSION:
+            raise TgcnError("tgcn_amd: freshly built library reports ABI %d, expected %d" % (probe.tgcn_abi_version(), ABI_VERSION))
+    except OSError as e:
+        os.unlink(tmp)
+        raise TgcnError("tgcn_amd: freshly built library does not load: %s" % e)
     os.replace(tmp, LIB_PATH)
     with open(stamp, "w") as f:
         f.write(want + "\n")
@@ -164,7 +173,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.tgcn_abi_version() != 4:
+        if handle.tgcn_abi_version() != ABI_VERSION:
             raise TgcnError("tgcn_amd: ABI version mismatch")
         _lib = handle
     return _lib
