@@ -15,14 +15,16 @@ def _coo(n, n_cols, nnz, rng, hubs=True):
     row = rng.integers(0, n, nnz)
     col = rng.integers(0, n_cols, nnz)
     if hubs and nnz > 1000:
-        row[: nnz // 5] = rng.integers(0, 3, nnz // 5)             # a few very long rows
-        col[nnz // 5: nnz // 3] = rng.integers(0, 2, nnz // 3 - nnz // 5)   # hub columns, many duplicates of one (row, col)
+        row[: nnz // 5] = rng.integers(0, min(3, n), nnz // 5)     # a few very long rows
+        col[nnz // 5: nnz // 3] = rng.integers(0, min(2, n_cols), nnz // 3 - nnz // 5)   # hub columns, many duplicates of one (row, col)
     val = rng.standard_normal(nnz).astype(np.float32)
     return torch.as_tensor(row).cuda(), torch.as_tensor(col).cuda(), torch.as_tensor(val).cuda()
 
 
 @pytest.mark.parametrize("n,n_cols,nnz", [(1, 1, 0), (7, 7, 1), (100, 100, 37), (1000, 1300, 50_000), (300_000, 300_000, 5_000_000),
-                                          (70_000, 20, 900_000), (5, 100_000, 400_000), (4096, 4096, 4096 * 16)])
+                                          (70_000, 20, 900_000), (5, 100_000, 400_000), (4096, 4096, 4096 * 16),
+                                          (1, 1, 5000), (1, 70_000, 300_000), (70_000, 1, 300_000), (20_000_000, 20_000_000, 3_000_000),
+                                          (257, 65_537, 4097), (65_536, 256, 4096), (3, 3, 2_000_000)])
 def test_csr_build_equals_torch_builder(n, n_cols, nnz, gpu_device, monkeypatch):
     from tgcn_amd import graph
     rng = np.random.default_rng(n + nnz)
@@ -47,11 +49,11 @@ def test_csr_build_rejects_out_of_range_indices(gpu_device):
 
 
 @pytest.mark.parametrize("C_row", [64, 16, 4, 300, 1])
-@pytest.mark.parametrize("n,nnz", [(50, 200), (3000, 40_000), (400_000, 6_000_000)])
+@pytest.mark.parametrize("n,nnz", [(50, 200), (3000, 40_000), (400_000, 6_000_000), (1, 40), (1, 5000), (40, 0), (2000, 2000 * 40), (5, 700_000)])
 def test_schedule_equals_torch_builder(n, nnz, C_row, gpu_device, monkeypatch):
     from tgcn_amd import graph, _lib
     rng = np.random.default_rng(n + C_row)
-    row, col, val = _coo(n, n, nnz, rng)
+    row, col, val = _coo(n, n, nnz, rng, hubs=n > 10)       # (1, 5000): one row of 157 segments; (2000, 80000): every row is cut into segments
     op = graph.GraphOperand.from_coo(n, row, col, val)
     lanes = _lib.lib().tgcn_hop_lanes_per_row(C_row, 1)
     lib_s = graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, builder="library")
