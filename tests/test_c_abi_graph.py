@@ -110,7 +110,7 @@ def test_library_schedule_equals_the_python_builder(lib, n):
         from tgcn_amd.graph import Schedule
         lanes = lib.tgcn_hop_lanes_per_row(C_row, 1)
         py = Schedule(op.rowptr, op.n, lanes, edges=op.edges, builder="torch")        # the torch index-op builder: the cross-check
-        for f in ("lanes_per_row", "row_thresh", "nblk", "nseg", "nlong", "nhuge", "npartial", "seg_mode", "row_mix"):
+        for f in ("lanes_per_row", "row_thresh", "nblk", "nseg", "nlong", "nhuge", "npartial", "seg_mode", "row_mix", "nwseg"):
             assert getattr(mine, f) == getattr(py.struct, f), f
         for f, cnt in (("blk_row", py.nblk + 1), ("seg_row", py.nseg), ("seg_e0", py.nseg), ("seg_e1", py.nseg), ("seg_slot", py.nseg),
                        ("long_row", py.nlong), ("long_slot", py.nlong + 1)):

@@ -58,7 +58,7 @@ def test_schedule_equals_torch_builder(n, nnz, C_row, gpu_device, monkeypatch):
     lanes = _lib.lib().tgcn_hop_lanes_per_row(C_row, 1)
     lib_s = graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, builder="library")
     py_s = graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, builder="torch")
-    for f in ("lanes_per_row", "row_thresh", "nblk", "nseg", "nlong", "nhuge", "npartial", "seg_mode", "row_mix"):
+    for f in ("lanes_per_row", "row_thresh", "nblk", "nseg", "nlong", "nhuge", "npartial", "seg_mode", "row_mix", "nwseg"):
         assert getattr(lib_s, f) == getattr(py_s, f), f
     for f, cnt in (("blk_row", py_s.nblk + 1), ("seg_row", py_s.nseg), ("seg_e0", py_s.nseg), ("seg_e1", py_s.nseg), ("seg_slot", py_s.nseg),
                    ("long_row", py_s.nlong), ("long_slot", py_s.nlong + 1 if py_s.nlong else 0)):

@@ -36,8 +36,14 @@ def test_schedule_covers_every_entry_once(lpr):
     for r in np.nonzero(deg <= s.row_thresh)[0]:
         covered[rowptr[r]:rowptr[r + 1]] += 1
     seg_row, e0, e1, slot = (t.numpy() for t in (s.seg_row, s.seg_e0, s.seg_e1, s.seg_slot))
+    wave_max = 32 * (64 // lpr) if lpr < 64 else 0
+    assert s.nwseg == int(((deg > s.row_thresh) & (deg <= wave_max)).sum())          # medium rows: one whole-row wave segment each
     for i in range(s.nseg):
-        assert rowptr[seg_row[i]] <= e0[i] < e1[i] <= rowptr[seg_row[i] + 1] and e1[i] - e0[i] <= s.seg_len
+        assert rowptr[seg_row[i]] <= e0[i] < e1[i] <= rowptr[seg_row[i] + 1]
+        if i < s.nwseg:
+            assert e0[i] == rowptr[seg_row[i]] and e1[i] == rowptr[seg_row[i] + 1] and s.row_thresh < e1[i] - e0[i] <= wave_max and slot[i] < 0
+        else:
+            assert e1[i] - e0[i] <= s.seg_len and deg[seg_row[i]] > max(wave_max, s.row_thresh)
         covered[e0[i]:e1[i]] += 1
         whole = (e0[i] == rowptr[seg_row[i]] and e1[i] == rowptr[seg_row[i] + 1])
         assert (slot[i] < 0) == whole
@@ -53,9 +59,9 @@ def test_schedule_covers_every_entry_once(lpr):
         assert np.array_equal(slot[mine], np.arange(long_slot[i], long_slot[i + 1]))
     nslots = np.diff(long_slot[: s.nlong + 1])
     assert np.all(nslots[: s.nhuge] > 64) and np.all(nslots[s.nhuge:] <= 64)
-    # segments are stored in order of their first column
+    # wave rows and lane-group segments are each stored in order of their first column
     first_col = op.edges[:, 0].numpy()[e0[: s.nseg]]
-    assert np.all(np.diff(first_col) >= 0)
+    assert np.all(np.diff(first_col[: s.nwseg]) >= 0) and np.all(np.diff(first_col[s.nwseg:]) >= 0)
 
 
 def test_dense_copy_of_small_dense_operands():

@@ -22,7 +22,7 @@ class CsrStruct(C.Structure):
 
 class SchedStruct(C.Structure):
     _fields_ = [("lanes_per_row", C.c_int32), ("row_thresh", C.c_int32), ("nblk", C.c_int32), ("nseg", C.c_int32),
-                ("nlong", C.c_int32), ("nhuge", C.c_int32), ("npartial", C.c_int32), ("seg_mode", C.c_int32), ("row_mix", C.c_int32), ("reserved", C.c_int32),
+                ("nlong", C.c_int32), ("nhuge", C.c_int32), ("npartial", C.c_int32), ("seg_mode", C.c_int32), ("row_mix", C.c_int32), ("nwseg", C.c_int32),
                 ("blk_row", C.c_void_p), ("seg_row", C.c_void_p), ("seg_e0", C.c_void_p), ("seg_e1", C.c_void_p),
                 ("seg_slot", C.c_void_p), ("long_row", C.c_void_p), ("long_slot", C.c_void_p)]
 

@@ -306,14 +306,16 @@ __global__ void edge_normalise_kernel(const int64_t* __restrict__ row, const int
 // --------------------------------------------------------------------------------------------------
 // schedule
 // --------------------------------------------------------------------------------------------------
-// cost[i] = (entries of row i if <= row_thresh else 0) + row_cost;  is_seg[i] = entries > row_thresh
-__global__ void sched_cost_kernel(const int32_t* __restrict__ rowptr, int64_t n, int row_thresh, int row_cost, int64_t* __restrict__ cost,
-                                  int64_t* __restrict__ is_seg, unsigned long long* __restrict__ n_empty) {
+// cost[i] = (entries of row i if <= row_thresh else 0) + row_cost;  is_seg[i] = entries > wave_max (rows cut into lane-group segments);
+// is_wave[i] = row_thresh < entries <= wave_max (whole-row wave segments; wave_max = row_thresh: none)
+__global__ void sched_cost_kernel(const int32_t* __restrict__ rowptr, int64_t n, int row_thresh, int wave_max, int row_cost, int64_t* __restrict__ cost,
+                                  int64_t* __restrict__ is_seg, int64_t* __restrict__ is_wave, unsigned long long* __restrict__ n_empty) {
   unsigned long long mine = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t d = rowptr[i + 1] - rowptr[i];
     cost[i] = (d > row_thresh ? 0 : d) + row_cost;
-    is_seg[i] = d > row_thresh ? 1 : 0;
+    is_seg[i] = d > wave_max ? 1 : 0;
+    is_wave[i] = (d > row_thresh && d <= wave_max) ? 1 : 0;
     mine += (d == 0);
   }
   if (mine) atomicAdd(n_empty, mine);      // integer count: order-independent
@@ -341,6 +343,26 @@ __global__ void sched_longrows_kernel(const int32_t* __restrict__ rowptr, int64_
     const int64_t o = pos[i];
     seg_rows[o] = (uint32_t)i;
     key[o] = max_key - (uint32_t)((d + seg_len - 1) / seg_len);
+  }
+}
+
+// whole-row wave segments, in row order: rows[pos[i]] = i, key = first column of the row
+__global__ void sched_waverows_kernel(const int32_t* __restrict__ rowptr, const tgcn_edge* __restrict__ edges, int64_t n, const int64_t* __restrict__ is_wave,
+                                      const int64_t* __restrict__ pos, uint32_t* __restrict__ rows, uint32_t* __restrict__ key) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (!is_wave[i]) continue;
+    const int64_t o = pos[i];
+    rows[o] = (uint32_t)i;
+    key[o] = (uint32_t)edges[rowptr[i]].col;
+  }
+}
+
+// the sorted wave rows as the first nw entries of the segment arrays
+__global__ void sched_wavesegs_kernel(const int32_t* __restrict__ rowptr, const uint32_t* __restrict__ rows, int64_t nw, int32_t* __restrict__ seg_row,
+                                      int32_t* __restrict__ seg_e0, int32_t* __restrict__ seg_e1, int32_t* __restrict__ seg_slot) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows[i];
+    seg_row[i] = (int32_t)r; seg_e0[i] = rowptr[r]; seg_e1[i] = rowptr[r + 1]; seg_slot[i] = -1;
   }
 }
 

@@ -168,28 +168,31 @@ int tgcn_sched_build_csr(const tgcn_csr* A, int64_t n_cols, int32_t C, int align
   tgcn_sched* sc = new (std::nothrow) tgcn_sched();
   if (!sc) TGCN_FAIL(TGCN_ERR_LAUNCH, "sched_build: out of host memory");
 #define TGCN_SCHED_FAIL(...) do { delete sc; TGCN_FAIL(TGCN_ERR_LAUNCH, __VA_ARGS__); } while (0)
-  // ---- short rows: nnz-balanced row blocks (cost = entries + 4 per row; rows cut into segments cost 4)
-  DeviceBuf cost, is_seg, pos, scanws, empties;
-  if (empties.zero(8) || cost.alloc((size_t)n * 8) || is_seg.alloc((size_t)(n + 1) * 8) || pos.alloc((size_t)(n + 1) * 8) || scanws.alloc(scan_ws_elems(n + 1) * 8) ||
-      hipMemset(is_seg.p, 0, (size_t)(n + 1) * 8) != hipSuccess)
+  // ---- short rows: nnz-balanced row blocks (cost = entries + 4 per row; rows that become segments cost 4)
+  const int32_t wave_max = lanes < 64 ? 32 * (64 / lanes) : row_thresh;      // row_thresh < entries <= wave_max: whole-row wave segments (nwseg)
+  DeviceBuf cost, is_seg, is_wave, pos, posw, scanws, empties;
+  if (empties.zero(8) || cost.alloc((size_t)n * 8) || is_seg.zero((size_t)(n + 1) * 8) || is_wave.zero((size_t)(n + 1) * 8) || pos.alloc((size_t)(n + 1) * 8) ||
+      posw.alloc((size_t)(n + 1) * 8) || scanws.alloc(scan_ws_elems(n + 1) * 8))
     TGCN_SCHED_FAIL("sched_build: device allocation failed");
-  hipLaunchKernelGGL(sched_cost_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, st, A->rowptr, n, (int)row_thresh, (int)row_cost, (int64_t*)cost.p, (int64_t*)is_seg.p,
-                     (unsigned long long*)empties.p);
+  hipLaunchKernelGGL(sched_cost_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, st, A->rowptr, n, (int)row_thresh, (int)wave_max, (int)row_cost, (int64_t*)cost.p,
+                     (int64_t*)is_seg.p, (int64_t*)is_wave.p, (unsigned long long*)empties.p);
   scan_i64(st, (const int64_t*)cost.p, (int64_t*)cost.p, n, 1, (int64_t*)scanws.p);                   // cum = inclusive prefix sum
-  scan_i64(st, (const int64_t*)is_seg.p, (int64_t*)pos.p, n + 1, 0, (int64_t*)scanws.p);              // pos[n] = rows cut into segments
-  int64_t total = 0, m = 0, n_empty = 0;
-  if (read_back(&total, (const int64_t*)cost.p + (n - 1)) || read_back(&m, (const int64_t*)pos.p + n) || read_back(&n_empty, (const int64_t*)empties.p))
+  scan_i64(st, (const int64_t*)is_seg.p, (int64_t*)pos.p, n + 1, 0, (int64_t*)scanws.p);              // pos[n] = rows cut into lane-group segments
+  scan_i64(st, (const int64_t*)is_wave.p, (int64_t*)posw.p, n + 1, 0, (int64_t*)scanws.p);            // posw[n] = whole-row wave segments
+  int64_t total = 0, m = 0, mw = 0, n_empty = 0;
+  if (read_back(&total, (const int64_t*)cost.p + (n - 1)) || read_back(&m, (const int64_t*)pos.p + n) || read_back(&mw, (const int64_t*)posw.p + n) ||
+      read_back(&n_empty, (const int64_t*)empties.p))
     TGCN_SCHED_FAIL("sched_build: device read failed");
   const int64_t cap = lanes <= 16 ? 64 : 256;        // narrow rows: small blocks keep an XCD's gather window inside its L2 (tgcn_amd/graph.py)
   const int64_t target = std::max<int64_t>(gpb * 16, std::min<int64_t>(gpb * cap, (total + max_blocks_hint - 1) / max_blocks_hint));
   const int64_t nblk = std::max<int64_t>(1, (total + target - 1) / target);
   if (sc->blk_row.alloc((size_t)(nblk + 1) * 4)) TGCN_SCHED_FAIL("sched_build: device allocation failed");
   hipLaunchKernelGGL(sched_marks_kernel, dim3(grid_1d(nblk + 1)), dim3(kBlock), 0, st, (const int64_t*)cost.p, n, target, nblk, (int32_t*)sc->blk_row.p);
-  // ---- longer rows: segments; rows with several segments ("long") first, by decreasing segment count (stable)
-  int64_t nlong = 0, nhuge = 0, npartial = 0, nseg = 0;
+  // ---- longest rows: lane-group segments; rows with several segments ("long") first, by decreasing segment count (stable)
+  int64_t nlong = 0, nhuge = 0, npartial = 0, nsegl = 0;
+  DeviceBuf seg_rows, key, sortws, nsegs, first, cnt2;
   if (m > 0) {
     const uint32_t max_key = (uint32_t)((A->nnz + seg_len - 1) / seg_len + 1);
-    DeviceBuf seg_rows, key, sortws, nsegs, first, cnt2;
     if (seg_rows.alloc((size_t)m * 4) || key.alloc((size_t)m * 4) || sortws.alloc(sort_ws_bytes(m)) || nsegs.zero((size_t)(m + 1) * 8) ||
         first.alloc((size_t)(m + 1) * 8) || cnt2.alloc(16))
       TGCN_SCHED_FAIL("sched_build: device allocation failed");
@@ -200,38 +203,48 @@ int tgcn_sched_build_csr(const tgcn_csr* A, int64_t n_cols, int32_t C, int align
     hipLaunchKernelGGL(sched_counts_kernel, dim3(1), dim3(64), 0, st, (const int64_t*)nsegs.p, m, (int)huge_slots, (int64_t*)cnt2.p);
     scan_i64(st, (const int64_t*)nsegs.p, (int64_t*)first.p, m + 1, 0, (int64_t*)scanws.p);             // first[m] = number of segments
     int64_t h2[2] = {0, 0};
-    if (hipMemcpy(h2, cnt2.p, 16, hipMemcpyDeviceToHost) != hipSuccess || read_back(&nseg, (const int64_t*)first.p + m)) TGCN_SCHED_FAIL("sched_build: device read failed");
+    if (hipMemcpy(h2, cnt2.p, 16, hipMemcpyDeviceToHost) != hipSuccess || read_back(&nsegl, (const int64_t*)first.p + m)) TGCN_SCHED_FAIL("sched_build: device read failed");
     nlong = h2[0]; nhuge = h2[1];
     if (nlong > 0 && read_back(&npartial, (const int64_t*)first.p + nlong)) TGCN_SCHED_FAIL("sched_build: device read failed");
-    if (nseg >= (int64_t)INT32_MAX) TGCN_SCHED_FAIL("sched_build: too many segments");
-    DeviceBuf u_row, u_e0, u_e1, u_slot, key2, ident, sortws2;
-    const size_t sb = (size_t)nseg * 4;
-    if (u_row.alloc(sb) || u_e0.alloc(sb) || u_e1.alloc(sb) || u_slot.alloc(sb) || key2.alloc(sb) || ident.alloc(sb) || sortws2.alloc(sort_ws_bytes(nseg)) ||
-        sc->seg_row.alloc(sb) || sc->seg_e0.alloc(sb) || sc->seg_e1.alloc(sb) || sc->seg_slot.alloc(sb) || sc->long_row.alloc((size_t)(nlong ? nlong : 1) * 4) ||
-        sc->long_slot.zero((size_t)(nlong + 2) * 4))
+  }
+  const int64_t nseg = mw + nsegl;               // whole-row wave segments first, then the lane-group segments
+  if (nseg >= (int64_t)INT32_MAX) TGCN_SCHED_FAIL("sched_build: too many segments");
+  const size_t sball = (size_t)(nseg > 0 ? nseg : 1) * 4;
+  if (sc->seg_row.zero(sball) || sc->seg_e0.zero(sball) || sc->seg_e1.zero(sball) || sc->seg_slot.zero(sball) || sc->long_row.zero((size_t)(nlong ? nlong : 1) * 4) ||
+      sc->long_slot.zero((size_t)(nlong + 2) * 4))
+    TGCN_SCHED_FAIL("sched_build: device allocation failed");
+  DeviceBuf wrows, wkey, wsort, u_row, u_e0, u_e1, u_slot, key2, ident, sortws2;
+  if (mw > 0) {                                  // in order of their first column (stable: ties in row order)
+    if (wrows.alloc((size_t)mw * 4) || wkey.alloc((size_t)mw * 4) || wsort.alloc(sort_ws_bytes(mw))) TGCN_SCHED_FAIL("sched_build: device allocation failed");
+    hipLaunchKernelGGL(sched_waverows_kernel, dim3(grid_1d(n)), dim3(kBlock), 0, st, A->rowptr, A->edges, n, (const int64_t*)is_wave.p, (const int64_t*)posw.p,
+                       (uint32_t*)wrows.p, (uint32_t*)wkey.p);
+    radix_sort_pairs(st, (uint32_t*)wkey.p, (uint32_t*)wrows.p, mw, bits_for(n_cols), (char*)wsort.p);
+    hipLaunchKernelGGL(sched_wavesegs_kernel, dim3(grid_1d(mw)), dim3(kBlock), 0, st, A->rowptr, (const uint32_t*)wrows.p, mw, (int32_t*)sc->seg_row.p,
+                       (int32_t*)sc->seg_e0.p, (int32_t*)sc->seg_e1.p, (int32_t*)sc->seg_slot.p);
+  }
+  if (nsegl > 0) {
+    const size_t sb = (size_t)nsegl * 4;
+    if (u_row.alloc(sb) || u_e0.alloc(sb) || u_e1.alloc(sb) || u_slot.alloc(sb) || key2.alloc(sb) || ident.alloc(sb) || sortws2.alloc(sort_ws_bytes(nsegl)))
       TGCN_SCHED_FAIL("sched_build: device allocation failed");
-    hipLaunchKernelGGL(sched_segments_kernel, dim3(grid_1d(nseg)), dim3(kBlock), 0, st, A->rowptr, A->edges, (const uint32_t*)seg_rows.p, (const int64_t*)first.p, m,
-                       nseg, npartial, (int)seg_len, (int32_t*)u_row.p, (int32_t*)u_e0.p, (int32_t*)u_e1.p, (int32_t*)u_slot.p, (uint32_t*)key2.p, (uint32_t*)ident.p);
+    hipLaunchKernelGGL(sched_segments_kernel, dim3(grid_1d(nsegl)), dim3(kBlock), 0, st, A->rowptr, A->edges, (const uint32_t*)seg_rows.p, (const int64_t*)first.p, m,
+                       nsegl, npartial, (int)seg_len, (int32_t*)u_row.p, (int32_t*)u_e0.p, (int32_t*)u_e1.p, (int32_t*)u_slot.p, (uint32_t*)key2.p, (uint32_t*)ident.p);
     // processing order: by first column (stable)
-    radix_sort_pairs(st, (uint32_t*)key2.p, (uint32_t*)ident.p, nseg, bits_for(n_cols), (char*)sortws2.p);
-    const unsigned gs = grid_1d(nseg);
-    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_row.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_row.p, nseg);
-    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_e0.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_e0.p, nseg);
-    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_e1.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_e1.p, nseg);
-    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_slot.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_slot.p, nseg);
+    radix_sort_pairs(st, (uint32_t*)key2.p, (uint32_t*)ident.p, nsegl, bits_for(n_cols), (char*)sortws2.p);
+    const unsigned gs = grid_1d(nsegl);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_row.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_row.p + mw, nsegl);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_e0.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_e0.p + mw, nsegl);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_e1.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_e1.p + mw, nsegl);
+    hipLaunchKernelGGL(permute_i32_kernel, dim3(gs), dim3(kBlock), 0, st, (const int32_t*)u_slot.p, (const uint32_t*)ident.p, (int32_t*)sc->seg_slot.p + mw, nsegl);
     if (nlong > 0)
       hipLaunchKernelGGL(sched_long_kernel, dim3(grid_1d(nlong + 1)), dim3(kBlock), 0, st, (const uint32_t*)seg_rows.p, (const int64_t*)first.p, nlong, npartial,
                          (int32_t*)sc->long_row.p, (int32_t*)sc->long_slot.p);
-    if (hipStreamSynchronize(st) != hipSuccess) TGCN_SCHED_FAIL("sched_build: kernels failed");      // the scratch buffers die with this scope
-  } else {
-    if (sc->seg_row.zero(4) || sc->seg_e0.zero(4) || sc->seg_e1.zero(4) || sc->seg_slot.zero(4) || sc->long_row.zero(4) || sc->long_slot.zero(8))
-      TGCN_SCHED_FAIL("sched_build: device allocation failed");
   }
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) TGCN_SCHED_FAIL("sched_build: kernels failed");
 #undef TGCN_SCHED_FAIL
   memset(&sc->s, 0, sizeof(sc->s));
   sc->s.lanes_per_row = lanes; sc->s.row_thresh = row_thresh; sc->s.nblk = (int32_t)nblk; sc->s.nseg = (int32_t)nseg;
   sc->s.nlong = (int32_t)nlong; sc->s.nhuge = (int32_t)nhuge; sc->s.npartial = (int32_t)npartial; sc->s.seg_mode = seg_mode;
+  sc->s.nwseg = (int32_t)mw;
   sc->s.row_mix = (n_empty * 8 >= n) ? 1 : 0;            // many empty rows: their blocks among the segment blocks (tgcn_csr_sched.row_mix)
   sc->s.blk_row = (const int32_t*)sc->blk_row.p; sc->s.seg_row = (const int32_t*)sc->seg_row.p; sc->s.seg_e0 = (const int32_t*)sc->seg_e0.p;
   sc->s.seg_e1 = (const int32_t*)sc->seg_e1.p; sc->s.seg_slot = (const int32_t*)sc->seg_slot.p; sc->s.long_row = (const int32_t*)sc->long_row.p;

@@ -25,6 +25,7 @@ struct HopParams {
   float alpha, beta, gamma;
   int32_t nblk, nseg, nlong, nhuge, row_thresh;
   int32_t C, nb, nchunks, cpad, remap;
+  int32_t nwseg;                 // leading segments that are whole rows of up to 32 * (64 / LPR) entries, one WAVE each (no partial rows)
   int32_t mix_period;            // > 1: one row block every mix_period block ids (0 / 1: all row blocks first)
   int32_t stream_out;            // the output tensor is larger than the Infinity Cache: entries, results and partial rows with non-temporal hints
   int32_t seg_mode, seg_remap;   // seg_mode 1: one WAVE per segment (tgcn_csr_sched.seg_mode); seg_remap: XCD-contiguous segment ranges
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
     int sbid = bid - p.nblk;
     if (p.seg_remap) sbid = xcd_remap(sbid, (int)gridDim.x - p.nblk);
     if constexpr (LPR < 64 && R == 1) {
-      if (p.seg_mode == 1) {
+      const int nwblk = (p.nwseg + kBlock / 64 - 1) / (kBlock / 64);     // workgroups of the whole-row wave segments (hybrid schedule)
+      if (p.seg_mode == 1 || sbid < nwblk) {
         // One wave per segment of up to 32 * (64 / LPR) entries: its lane groups take consecutive pieces of the segment and the
         // pieces are folded inside the wave (fixed order: neighbours first), so a row of up to that many entries is written
         // directly and longer rows leave one partial row per wave instead of one per lane group.
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
         const int s = sbid * (kBlock / 64) + (tid >> 6);
         const int gw = (tid & 63) / LPR;
         int e0[1] = {0}, e1[1] = {0};
-        if (s < p.nseg) {
+        const int wlimit = p.seg_mode == 1 ? p.nseg : p.nwseg;
+        if (s < wlimit) {
           const int a = p.seg_e0[s], z = p.seg_e1[s];
           const int per = (z - a + GPW - 1) / GPW;
           e0[0] = min(z, a + gw * per);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
         for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[0][i] += __shfl_xor(acc[0][i], off, 64);
-        if (s >= p.nseg || gw != 0) return;
+        if (s >= wlimit || gw != 0) return;
         const int slot = p.seg_slot[s];
         if (slot < 0) {
           if (cact) finish_row<VEC, NTM>(p, b, p.seg_row[s], c0, acc[0]);
@@ -281,8 +284,9 @@ __global__ __launch_bounds__(kBlock) void hop_kernel(const HopParams p) {
         }
         return;
       }
+      sbid -= nwblk;
     }
-    const int sb = sbid * GPB * R + gib;
+    const int sb = p.nwseg + sbid * GPB * R + gib;
     int e0[R], e1[R];
     float acc[R][VEC];
 #pragma unroll
@@ -385,7 +389,8 @@ template <int LPR, int VEC, int U, int R, int NTM = 0>
 inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
   constexpr int GPB = kBlock / LPR;
   const int seg_per_block = (p.seg_mode == 1 && LPR < 64 && R == 1) ? kBlock / 64 : GPB * R;
-  grid.x = (unsigned)(p.nblk + (p.nseg + seg_per_block - 1) / seg_per_block);
+  const int nw = (LPR < 64 && R == 1 && p.seg_mode != 1) ? p.nwseg : 0;
+  grid.x = (unsigned)(p.nblk + (nw + kBlock / 64 - 1) / (kBlock / 64) + (p.nseg - nw + seg_per_block - 1) / seg_per_block);
   // "hop_lds_pad": unused dynamic LDS per workgroup = an occupancy limiter (160 KB / pad workgroups per CU) for A/B runs
   const int pad = g_hop_lds_pad.load();
   if (pad > 65536) allow_large_lds((const void*)hop_kernel<LPR, VEC, U, R, NTM>, pad);

@@ -147,9 +147,11 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
   p.nblk = S->nblk; p.nseg = S->nseg; p.nlong = S->nlong; p.nhuge = S->nhuge; p.row_thresh = S->row_thresh;
   p.C = C; p.nb = nb; p.nchunks = g.nchunks; p.cpad = g.cpad; p.remap = g_hop_remap.load();
   p.seg_mode = S->seg_mode; p.seg_remap = g_hop_seg_remap.load();
+  if (S->nwseg < 0 || S->nwseg > S->nseg || (S->nwseg > 0 && (S->seg_mode != 0 || g.lpr >= 64))) TGCN_FAIL(TGCN_ERR_INVALID, "hop: nwseg %d of %d segments", S->nwseg, S->nseg);
+  p.nwseg = S->nwseg;
   {
     const int seg_per_block = (S->seg_mode == 1 && g.lpr < 64) ? kBlock / 64 : kBlock / g.lpr;      // launch_hop's count (R = 1 where it matters)
-    const int64_t nsb = (S->nseg + seg_per_block - 1) / seg_per_block;
+    const int64_t nsb = (S->nwseg + kBlock / 64 - 1) / (kBlock / 64) + (S->nseg - S->nwseg + seg_per_block - 1) / seg_per_block;
     const int mix = g_hop_mix.load();
     p.mix_period = ((mix == 1 || (mix == 0 && S->row_mix)) && S->nblk > 0 && nsb >= S->nblk && g.lpr < 64) ? (int32_t)((S->nblk + nsb) / S->nblk) : (mix == 2 && nsb > 0 ? -1 : 0);
   }

@@ -16,6 +16,8 @@ SEG_LEN = 32            # stored entries per segment (measured on cfg5: 32 beats
 SEG_MODE = 0            # 0: one lane group per segment (shipped); 1: one WAVE per segment of SEG_LEN * (64 / lanes) entries, pieces folded in
                         # the wave -- 4.7x fewer partial rows but the column-ordered sweep loses its locality: cfg5 hop 3.82 -> 4.44 ms
 SEG_KEY = "first"       # column of the segment used as its place in the processing order
+WAVE_ROWS = True        # rows with ROW_THRESH < entries <= 32 * (64 / lanes) are whole-row segments of one WAVE each (its lane groups fold inside the
+                        # wave: no partial rows, no fix-up for them; cfg5: fix-up 0.216 -> 0.155 ms per launch, hop unchanged); False: lane-group segments
 HUGE_SLOTS = 64         # long rows with more segments than this get a whole workgroup in the fix-up
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
 DENSE_MAX_N = 256       # operands up to this size that store >= 1/4 of their entries also keep a dense copy
@@ -42,7 +44,7 @@ class Schedule:
 
     def __init__(self, rowptr, n, lanes_per_row, edges=None, row_thresh=None, seg_len=None, seg_mode=None, n_cols=None, builder=None):
         defaults = (row_thresh is None and seg_len is None and seg_mode is None and ROW_THRESH == 32 and SEG_LEN == 32 and SEG_MODE == 0
-                    and SEG_KEY == "first" and BLOCK_ROWS_MAX is None and ROW_COST == 4 and HUGE_SLOTS == 64 and MAX_BLOCKS_HINT == 2048)
+                    and SEG_KEY == "first" and WAVE_ROWS and BLOCK_ROWS_MAX is None and ROW_COST == 4 and HUGE_SLOTS == 64 and MAX_BLOCKS_HINT == 2048)
         builder = BUILDER if builder is None else builder
         if builder == "library" and rowptr.is_cuda and edges is not None and defaults:
             self._build_library(rowptr, n, lanes_per_row, edges, n if n_cols is None else n_cols)
@@ -77,7 +79,15 @@ class Schedule:
                                           torch.full((1,), n, dtype=torch.int64, device=dev)]))
         self.nblk = nblk
         # ---- longer rows: segments, long rows (several segments) first by decreasing segment count
-        seg_rows = is_seg.nonzero().flatten()
+        self.nwseg = 0
+        wave_rows = None
+        wave_max = 32 * (64 // lanes_per_row) if lanes_per_row < 64 else 0
+        if WAVE_ROWS and wave_max > row_thresh and seg_mode == 0 and edges is not None:
+            wave_rows = (is_seg & (deg <= wave_max)).nonzero().flatten()
+            is_seg_long = is_seg & (deg > wave_max)
+        else:
+            is_seg_long = is_seg
+        seg_rows = is_seg_long.nonzero().flatten()
         z1 = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nseg = self.nlong = self.nhuge = self.npartial = 0
         self.seg_row = self.seg_e0 = self.seg_e1 = self.seg_slot = self.long_row = z1
@@ -114,13 +124,25 @@ class Schedule:
                 perm = torch.argsort(key, stable=True)
                 row_of, e0, e1, slot = row_of[perm], e0[perm], e1[perm], slot[perm]
             self.seg_row, self.seg_e0, self.seg_e1, self.seg_slot = _as_i32(row_of), _as_i32(e0), _as_i32(e1), _as_i32(slot)
+        if wave_rows is not None and wave_rows.numel():
+            # whole rows of one wave each, in order of their first column, in FRONT of the lane-group segments
+            w0 = rowptr[wave_rows].to(torch.int64)
+            w1 = rowptr[wave_rows + 1].to(torch.int64)
+            wperm = torch.argsort(edges[w0, 0].to(torch.int64), stable=True)
+            wr, w0, w1 = wave_rows[wperm], w0[wperm], w1[wperm]
+            self.nwseg = int(wr.numel())
+            had = self.nseg
+            cat = lambda a, b: torch.cat([_as_i32(a), b[:had]]) if had else _as_i32(a)
+            self.seg_row, self.seg_e0, self.seg_e1 = cat(wr, self.seg_row), cat(w0, self.seg_e0), cat(w1, self.seg_e1)
+            self.seg_slot = cat(torch.full_like(wr, -1), self.seg_slot)
+            self.nseg = had + self.nwseg
         self.lanes_per_row = lanes_per_row
         self.row_thresh = row_thresh
         self.seg_len = seg_len
         self.seg_mode = seg_mode
         # >= 1/8 structurally empty rows: their row blocks (mostly streaming zero writes) are dealt among the segment blocks
         self.row_mix = int(int((deg == 0).sum().item()) * 8 >= n)
-        self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, seg_mode, self.row_mix, 0,
+        self.struct = _lib.SchedStruct(lanes_per_row, row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, seg_mode, self.row_mix, self.nwseg,
                                        self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(),
                                        self.seg_e1.data_ptr(), self.seg_slot.data_ptr(), self.long_row.data_ptr(),
                                        self.long_slot.data_ptr())
@@ -150,11 +172,11 @@ def _sched_build_library(self, rowptr, n, lanes_per_row, edges, n_cols):
             self.long_slot = torch.zeros(max(st.nlong + 1, 2), dtype=torch.int32, device=dev)
             _lib.check(L.tgcn_sched_copy(h, _lib.stream_ptr(), _lib.ptr(self.blk_row), _lib.ptr(self.seg_row), _lib.ptr(self.seg_e0),
                                          _lib.ptr(self.seg_e1), _lib.ptr(self.seg_slot), _lib.ptr(self.long_row), _lib.ptr(self.long_slot)))
-            self.lanes_per_row, self.row_thresh, self.seg_len, self.seg_mode, self.row_mix = st.lanes_per_row, st.row_thresh, 32, st.seg_mode, st.row_mix
+            self.lanes_per_row, self.row_thresh, self.seg_len, self.seg_mode, self.row_mix, self.nwseg = st.lanes_per_row, st.row_thresh, 32, st.seg_mode, st.row_mix, st.nwseg
         finally:
             L.tgcn_sched_destroy(h)
     self.struct = _lib.SchedStruct(self.lanes_per_row, self.row_thresh, self.nblk, self.nseg, self.nlong, self.nhuge, self.npartial, self.seg_mode,
-                                   self.row_mix, 0, self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(), self.seg_e1.data_ptr(),
+                                   self.row_mix, self.nwseg, self.blk_row.data_ptr(), self.seg_row.data_ptr(), self.seg_e0.data_ptr(), self.seg_e1.data_ptr(),
                                    self.seg_slot.data_ptr(), self.long_row.data_ptr(), self.long_slot.data_ptr())
 
 

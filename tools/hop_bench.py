@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--mix", default="0", help="comma list of hop_mix values (row blocks dealt among the segment blocks)")
     ap.add_argument("--compact", action="store_true", help="time the hop on the compacted operand (graph.CompactPlan.rest: only rows with entries)")
     ap.add_argument("--drop-core", type=int, default=None, help="remove the entries whose row AND column are among the H vertices of largest degree (what a hub-core kernel would take over)")
+    ap.add_argument("--no-wave-rows", action="store_true", help="graph.WAVE_ROWS = False: medium rows as lane-group segments too")
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     args = ap.parse_args()
     from tools import synth
@@ -46,6 +47,7 @@ def main():
     graph.SEG_KEY = args.seg_key
     if args.block_cost:
         graph.BLOCK_ROWS_MAX = args.block_cost
+    graph.WAVE_ROWS = not args.no_wave_rows
     dev = torch.device("cuda:0")
     if args.graph == "mesh":
         args.n, row, col, val = synth.sheet_mesh(300, device=dev)
@@ -77,7 +79,7 @@ def main():
     lanes = _lib.lib().tgcn_hop_lanes_per_row(args.C // args.split, 1)
     scheds = {m: graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, seg_mode=m, n_cols=op.n_cols) for m in sorted(set(int(m) for m in args.seg_modes.split(",")))}
     for m, sm in scheds.items():
-        print("seg_mode %d: blocks=%d segments=%d long rows=%d huge=%d partial slots=%d seg_len=%d" % (m, sm.nblk, sm.nseg, sm.nlong, sm.nhuge, sm.npartial, sm.seg_len), flush=True)
+        print("seg_mode %d: blocks=%d segments=%d (whole-row wave segments %d) long rows=%d huge=%d partial slots=%d seg_len=%d" % (m, sm.nblk, sm.nseg, getattr(sm, "nwseg", 0), sm.nlong, sm.nhuge, sm.npartial, sm.seg_len), flush=True)
     s = op.schedule_for(args.C // args.split)
     print("n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d)" % (op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len), flush=True)
     x = torch.randn(1, op.n_cols, args.C, device=dev)
