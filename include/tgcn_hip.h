@@ -54,7 +54,7 @@ typedef struct tgcn_csr {
  *   rows with <= row_thresh stored entries: nnz-balanced row blocks, one workgroup each, one lane group per row;
  *   longer rows: segments of bounded length, STORED IN ORDER OF THEIR FIRST COLUMN so that the groups in flight
  *   gather from the same region of the dense operand at about the same time (hub columns then hit in L2).
- *   Rows of more than row_thresh but at most 32 * (64 / lanes_per_row) entries are one whole-row segment handled by ONE WAVE (nwseg);
+ *   16-lane schedules: rows of more than row_thresh but at most 128 entries are one whole-row segment handled by ONE WAVE (nwseg);
  *   A segment that is its whole row writes the row directly (seg_slot = -1); rows cut into several segments
  *   ("long rows") sum them through numbered scratch slots that a fix-up launch folds in slot order, so results
  *   do not depend on timing.  The first nhuge long rows (most slots) get a whole workgroup each in the fix-up.
@@ -73,7 +73,8 @@ typedef struct tgcn_csr_sched {
   int32_t row_mix;  /* 1: row blocks dealt evenly among the segment blocks instead of all in front -- set by the builders for operands with
                        >= 1/8 structurally empty rows, whose row blocks are mostly streaming zero writes that fill the gaps of the
                        gather-bound segments (uncompacted R-MAT: 4.25 -> 3.95 ms per launch); 0 otherwise (it costs 2.5 % there) */
-  int32_t nwseg;    /* leading entries of the seg_* arrays that are WHOLE rows of row_thresh < entries <= 32 * (64 / lanes_per_row), in
+  int32_t nwseg;    /* leading entries of the seg_* arrays that are WHOLE rows of row_thresh < entries <= 32 * (64 / lanes_per_row) (the builders
+                       use them for 16-lane schedules only), in
                        order of their first column: one wave each (its lane groups take consecutive pieces, folded inside the wave), written
                        directly -- no partial rows, no fix-up for them.  The remaining nseg - nwseg entries are the lane-group segments
                        of the longer rows.  0 for 64-lane schedules */

@@ -36,7 +36,7 @@ def test_schedule_covers_every_entry_once(lpr):
     for r in np.nonzero(deg <= s.row_thresh)[0]:
         covered[rowptr[r]:rowptr[r + 1]] += 1
     seg_row, e0, e1, slot = (t.numpy() for t in (s.seg_row, s.seg_e0, s.seg_e1, s.seg_slot))
-    wave_max = 32 * (64 // lpr) if lpr < 64 else 0
+    wave_max = 128 if lpr == 16 else 0          # whole-row wave segments: 16-lane schedules only
     assert s.nwseg == int(((deg > s.row_thresh) & (deg <= wave_max)).sum())          # medium rows: one whole-row wave segment each
     for i in range(s.nseg):
         assert rowptr[seg_row[i]] <= e0[i] < e1[i] <= rowptr[seg_row[i] + 1]

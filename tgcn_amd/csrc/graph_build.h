@@ -169,7 +169,9 @@ int tgcn_sched_build_csr(const tgcn_csr* A, int64_t n_cols, int32_t C, int align
   if (!sc) TGCN_FAIL(TGCN_ERR_LAUNCH, "sched_build: out of host memory");
 #define TGCN_SCHED_FAIL(...) do { delete sc; TGCN_FAIL(TGCN_ERR_LAUNCH, __VA_ARGS__); } while (0)
   // ---- short rows: nnz-balanced row blocks (cost = entries + 4 per row; rows that become segments cost 4)
-  const int32_t wave_max = lanes < 64 ? 32 * (64 / lanes) : row_thresh;      // row_thresh < entries <= wave_max: whole-row wave segments (nwseg)
+  // row_thresh < entries <= wave_max: whole-row wave segments (nwseg).  16-lane groups only: with 4-lane groups a wave is 16 groups and a
+  // 40-entry row leaves most of them idle (cfg5n: hop +8 %); other widths unmeasured
+  const int32_t wave_max = lanes == 16 ? 32 * (64 / lanes) : row_thresh;
   DeviceBuf cost, is_seg, is_wave, pos, posw, scanws, empties;
   if (empties.zero(8) || cost.alloc((size_t)n * 8) || is_seg.zero((size_t)(n + 1) * 8) || is_wave.zero((size_t)(n + 1) * 8) || pos.alloc((size_t)(n + 1) * 8) ||
       posw.alloc((size_t)(n + 1) * 8) || scanws.alloc(scan_ws_elems(n + 1) * 8))

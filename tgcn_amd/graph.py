@@ -16,7 +16,7 @@ SEG_LEN = 32            # stored entries per segment (measured on cfg5: 32 beats
 SEG_MODE = 0            # 0: one lane group per segment (shipped); 1: one WAVE per segment of SEG_LEN * (64 / lanes) entries, pieces folded in
                         # the wave -- 4.7x fewer partial rows but the column-ordered sweep loses its locality: cfg5 hop 3.82 -> 4.44 ms
 SEG_KEY = "first"       # column of the segment used as its place in the processing order
-WAVE_ROWS = True        # rows with ROW_THRESH < entries <= 32 * (64 / lanes) are whole-row segments of one WAVE each (its lane groups fold inside the
+WAVE_ROWS = True        # 16-lane schedules: rows with ROW_THRESH < entries <= 128 are whole-row segments of one WAVE each (its lane groups fold inside the
                         # wave: no partial rows, no fix-up for them; cfg5: fix-up 0.216 -> 0.155 ms per launch, hop unchanged); False: lane-group segments
 HUGE_SLOTS = 64         # long rows with more segments than this get a whole workgroup in the fix-up
 ROW_COST = 4            # per-row overhead of the balance model, in entry equivalents
@@ -81,7 +81,8 @@ class Schedule:
         # ---- longer rows: segments, long rows (several segments) first by decreasing segment count
         self.nwseg = 0
         wave_rows = None
-        wave_max = 32 * (64 // lanes_per_row) if lanes_per_row < 64 else 0
+        # 16-lane groups only: with 4-lane groups (cfg5n) a wave is 16 groups and a 40-entry row leaves most of them idle (hop +8 %)
+        wave_max = 32 * (64 // lanes_per_row) if lanes_per_row == 16 else 0
         if WAVE_ROWS and wave_max > row_thresh and seg_mode == 0 and edges is not None:
             wave_rows = (is_seg & (deg <= wave_max)).nonzero().flatten()
             is_seg_long = is_seg & (deg > wave_max)
