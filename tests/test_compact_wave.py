@@ -201,6 +201,16 @@ def test_offsets_beyond_2_31_elements(gpu_device):
             ref_last = last
         else:
             assert float((last - ref_last).abs().max() / ref_last.abs().max()) <= 1e-6
+    # the hop itself with the batch inside ONE launch (in-kernel b * batch_stride beyond 2^31 elements): last sample == computed alone,
+    # and the adjoint identity <L x, y> = <x, L^T y> on that sample
+    yb = F.csr_hop(op, x)
+    y8 = F.csr_hop(op, x[q - 1:q].clone())
+    assert torch.equal(yb[q - 1], y8[0])
+    w = torch.randn(1, n, C, device="cuda", generator=g)
+    lhs_a = (y8.double() * w.double()).sum()
+    rhs_a = (x[q - 1:q].double() * F.csr_hop(op.transpose(), w).double()).sum()
+    assert abs(lhs_a - rhs_a) <= 1e-6 * max(abs(lhs_a), abs(rhs_a), 1.0)
+    del yb, y8, w
     # linearity on the last sample: A(0.5 a + b) = 0.5 A a + A b
     a, b = x[q - 1:q], x[0:1]
     lhs = F.cheb_forward_compact(plan, 0.5 * a + b, W, None, 0, K)
