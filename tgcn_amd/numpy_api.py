@@ -27,11 +27,16 @@ def _chebyshev_f64(L, X, K, device):
     from . import _lib
     # the caller's matrix is never touched (tocsr() of a CSR returns the object itself), and entries keep their stored order,
     # which is the order the reference's L.dot sums them in (gcn/graph.py:256-265)
-    Lc = L.tocsr() if hasattr(L, "tocsr") else __import__("scipy.sparse").sparse.csr_matrix(np.asarray(L))
-    n = Lc.shape[0]
-    rp = torch.as_tensor(Lc.indptr.astype(np.int32), device=device)
-    ci = torch.as_tensor(Lc.indices.astype(np.int32), device=device)
-    va = torch.as_tensor(Lc.data.astype(np.float64), device=device)
+    key = ("f64", id(L), getattr(L, "nnz", None), _fingerprint(L), str(device))
+    hit = _cache.get(key)
+    if hit is None:                      # the device CSR is kept like the fp32 operand (gcn_mnist.py calls this per batch with one L)
+        Lc = L.tocsr() if hasattr(L, "tocsr") else __import__("scipy.sparse").sparse.csr_matrix(np.asarray(L))
+        if len(_cache) > 8:
+            _cache.clear()
+        hit = _cache[key] = ((Lc.shape[0], torch.as_tensor(Lc.indptr.astype(np.int32), device=device),
+                              torch.as_tensor(Lc.indices.astype(np.int32), device=device),
+                              torch.as_tensor(Lc.data.astype(np.float64), device=device)), L)      # L kept alive: a freed object's id can come back
+    n, rp, ci, va = hit[0]
     lib = _lib.lib()
 
     def hop(x, z, alpha, beta, y, p):
