@@ -338,7 +338,11 @@ int tgcn_relu_pool_f32(void* stream, const float* x, float* out, uint8_t* idx, i
  * out (q, n/pool, N), pool_idx (nullable) as above.  On the (q, n, C) layout with up to 32 terms and N <= 64 output columns
  * the epilogue runs inside the projection kernel (bias, relu and the max over 2 / 4 / 8 / 16 rows of the finished tile), so the
  * (q, n, N) layer output is never written; other shapes run the layer into workspace scratch followed by tgcn_relu_pool_f32
- * (the workspace query accounts for it).  pool = 1: relu only. */
+ * (the workspace query accounts for it; it returns 0 only for invalid arguments -- a K = 1 layer on a schedule without partial rows has
+ * a base figure of 0 and still gets its output scratch).  pool = 1: relu only.
+ * Alignment: the fused epilogue needs `out` and `bias` 16-byte aligned and `pool_idx` 4-byte aligned.  The query decides fused vs two-pass
+ * from the shape alone; a call with a fusable shape and a misaligned pointer takes the two-pass form when the workspace also holds
+ * q*n*N floats of scratch behind the queried size, and fails with TGCN_ERR_INVALID (message names the pointers) otherwise. */
 size_t tgcn_cheb_forward_pool_workspace_bytes(const tgcn_csr_sched* sched, int32_t K, int64_t q, int64_t n, int32_t C, int32_t N,
                                               int32_t layout, int64_t q_chunk, int32_t pool);
 int tgcn_cheb_forward_pool_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t mode, int32_t K, int64_t q,

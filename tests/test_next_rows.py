@@ -191,7 +191,8 @@ def test_reordered_operand_in_forward_series_and_to(kind, gpu_device):
     assert rel_err(lb.bias.grad.cpu().numpy(), la.bias.grad.cpu().numpy()) <= 2e-5
 
 
-@pytest.mark.parametrize("case", ["mesh59k_gcn32x64_pool4", "mesh90k_tgcn64x64_pool2", "grid_exact_pool4", "mesh_layout1_fallback"])
+@pytest.mark.parametrize("case", ["mesh59k_gcn32x64_pool4", "mesh90k_tgcn64x64_pool2", "grid_exact_pool4", "mesh_layout1_fallback",
+                                  "mesh_k1_wide_fallback"])
 def test_relu_pool_in_the_projection_epilogue(case, gpu_device):
     """SURVEY 8f-2 for graphs that do not fit in LDS: bias + relu + max over 2 / 4 consecutive vertices inside the projection's
     epilogue (tgcn_cheb_forward_pool_f32) -- against the ORACLE's pool(relu(forward)) on the 59,536-vertex mesh and at 90 k
@@ -212,6 +213,10 @@ def test_relu_pool_in_the_projection_epilogue(case, gpu_device):
     elif case == "grid_exact_pool4":              # small problem: the exact-fp32 W-resident kernel's epilogue
         n, row, col, val = synth.sheet_mesh(40)
         mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 32, 16, 3)), 2, 32, 4, True
+        ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
+    elif case == "mesh_k1_wide_fallback":         # K = 1 on a schedule without partial rows has a base workspace of 0 bytes, and
+        n, row, col, val = synth.sheet_mesh(100)  # 96 output columns cannot take the fused epilogue: the query must still size the output scratch
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 64, 96, 1)), 1, 64, 4, False
         ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
     else:
         n, row, col, val = synth.sheet_mesh(60)

@@ -54,6 +54,19 @@ inline void allow_large_lds(const void* fn, int bytes) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);   // a refusal surfaces as a launch error
 }
 
+// Compute units of the calling thread's current device (256 on MI355X), read once per device: round sizes of one-workgroup-per-CU
+// kernels follow from it instead of a literal.
+inline int cu_count() {
+  static std::atomic<int> cached[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cached[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
 std::atomic<int> g_hop_variant{0};
 std::atomic<int> g_hop_remap{1};        // hop_kernel: row blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)
 std::atomic<int> g_hop_seg_remap{0};    // hop_kernel: segment blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)

@@ -20,7 +20,9 @@ constexpr int kScanPer = 8;                       // elements per thread
 constexpr int kScanTile = kBlock * kScanPer;      // elements per workgroup
 
 // out[i] = sum of in[0..i) (exclusive) or in[0..i] (inclusive) within the tile; tile_sums[tile] = the tile's total
-__global__ __launch_bounds__(kBlock) void scan_tile_kernel(const int64_t* __restrict__ in, int64_t* __restrict__ out,
+// in and out may be the SAME array (scan_i64 is called in place for the radix histogram, counts -> rowptr and the cost prefix): no
+// __restrict__ on them; every thread loads its elements into registers before its first store.
+__global__ __launch_bounds__(kBlock) void scan_tile_kernel(const int64_t* in, int64_t* out,
                                                            int64_t* __restrict__ tile_sums, int64_t n, int inclusive) {
   __shared__ int64_t wave_tot[kBlock / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -26,7 +26,7 @@ struct HopParams {
   int32_t nblk, nseg, nlong, nhuge, row_thresh;
   int32_t C, nb, nchunks, cpad, remap;
   int32_t nwseg;                 // leading segments that are whole rows of up to 32 * (64 / LPR) entries, one WAVE each (no partial rows)
-  int32_t mix_period;            // > 1: one row block every mix_period block ids (0 / 1: all row blocks first)
+  int32_t mix_period;            // kernel: > 1 one row block every mix_period block ids, < 0 segment blocks first, 0 / 1 row blocks first (host: the request, see launch_hop)
   int32_t stream_out;            // the output tensor is larger than the Infinity Cache: entries, results and partial rows with non-temporal hints
   int32_t seg_mode, seg_remap;   // seg_mode 1: one WAVE per segment (tgcn_csr_sched.seg_mode); seg_remap: XCD-contiguous segment ranges
 };
@@ -390,11 +390,16 @@ inline void launch_hop(hipStream_t st, const HopParams& p, dim3 grid) {
   constexpr int GPB = kBlock / LPR;
   const int seg_per_block = (p.seg_mode == 1 && LPR < 64 && R == 1) ? kBlock / 64 : GPB * R;
   const int nw = (LPR < 64 && R == 1 && p.seg_mode != 1) ? p.nwseg : 0;
-  grid.x = (unsigned)(p.nblk + (nw + kBlock / 64 - 1) / (kBlock / 64) + (p.nseg - nw + seg_per_block - 1) / seg_per_block);
+  const int nsb = (nw + kBlock / 64 - 1) / (kBlock / 64) + (p.nseg - nw + seg_per_block - 1) / seg_per_block;
+  grid.x = (unsigned)(p.nblk + nsb);
+  HopParams pk = p;
+  // p.mix_period arrives as a request (tgcn_csr_hop_f32); the period follows from THIS kernel's segment-block count
+  if (p.mix_period > 0) pk.mix_period = (p.nblk > 0 && nsb >= p.nblk && LPR < 64) ? (p.nblk + nsb) / p.nblk : 0;
+  else if (p.mix_period < 0) pk.mix_period = nsb > 0 ? -1 : 0;
   // "hop_lds_pad": unused dynamic LDS per workgroup = an occupancy limiter (160 KB / pad workgroups per CU) for A/B runs
   const int pad = g_hop_lds_pad.load();
   if (pad > 65536) allow_large_lds((const void*)hop_kernel<LPR, VEC, U, R, NTM>, pad);
-  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, NTM>), grid, dim3(kBlock), (size_t)(pad > 0 ? pad : 0), st, p);
+  hipLaunchKernelGGL((hop_kernel<LPR, VEC, U, R, NTM>), grid, dim3(kBlock), (size_t)(pad > 0 ? pad : 0), st, pk);
 }
 
 // developer variants of the two float4 shapes that matter for the benchmarks (tools/hop_bench.py)

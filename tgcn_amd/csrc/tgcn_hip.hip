@@ -150,10 +150,10 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
   if (S->nwseg < 0 || S->nwseg > S->nseg || (S->nwseg > 0 && (S->seg_mode != 0 || g.lpr >= 64))) TGCN_FAIL(TGCN_ERR_INVALID, "hop: nwseg %d of %d segments", S->nwseg, S->nseg);
   p.nwseg = S->nwseg;
   {
-    const int seg_per_block = (S->seg_mode == 1 && g.lpr < 64) ? kBlock / 64 : kBlock / g.lpr;      // launch_hop's count (R = 1 where it matters)
-    const int64_t nsb = (S->nwseg + kBlock / 64 - 1) / (kBlock / 64) + (S->nseg - S->nwseg + seg_per_block - 1) / seg_per_block;
+    // the REQUEST only (1: row blocks dealt among the segment blocks, -1: segment blocks first); launch_hop turns it into the
+    // period once it knows the real number of segment blocks of the kernel it launches (rows interleaved per group differ by variant)
     const int mix = g_hop_mix.load();
-    p.mix_period = ((mix == 1 || (mix == 0 && S->row_mix)) && S->nblk > 0 && nsb >= S->nblk && g.lpr < 64) ? (int32_t)((S->nblk + nsb) / S->nblk) : (mix == 2 && nsb > 0 ? -1 : 0);
+    p.mix_period = (mix == 1 || (mix == 0 && S->row_mix)) ? 1 : (mix == 2 ? -1 : 0);
   }
   p.stream_out = ((int64_t)A->n * C * (int64_t)sizeof(float) * nb > ((int64_t)256 << 20)) && g_hop_stream.load();
   const int gpb = kBlock / g.lpr;
@@ -293,7 +293,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     const size_t lds = wbytes + (size_t)kResScratchFloats * sizeof(float);
     const int64_t ntiles = (M + res_rows - 1) / res_rows;
     int64_t gx = (ntiles + res_waves - 1) / res_waves;
-    if (gx > 256) gx = 256;    // one persistent workgroup per CU (LDS-limited residency)
+    if (gx > cu_count()) gx = cu_count();    // one persistent workgroup per CU (LDS-limited residency)
     const dim3 grid((unsigned)gx, gy);
     ProfScope ps(TGCN_PROF_PROJECT, st);
 #define TGCN_PROJ_R(NTV, V4)                                                                                  \
@@ -332,9 +332,9 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     const dim3 grid3((unsigned)gx3, grid.y);
     // project_x3v2_kernel runs one workgroup per CU: when the last round of 256-row tiles would fill at most ~60 % of the CUs,
     // its rows go out as 128-row tiles (twice the workgroups, about half the duration each)
-    const int64_t B = (M + 255) / 256, rem = B % 256;
+    const int64_t B = (M + 255) / 256, rem = B % cu_count();
     int64_t main_blocks = B, tail_blocks = 0;
-    if (rem != 0 && rem <= 160 && g_x3_tail.load()) {
+    if (rem != 0 && rem * 8 <= (int64_t)cu_count() * 5 && g_x3_tail.load()) {
       main_blocks = B - rem;
       tail_blocks = (M - main_blocks * 256 + 127) / 128;
     }
@@ -646,8 +646,10 @@ static bool forward_pool_fusable(int32_t K, int64_t q, int64_t n, int32_t C, int
 
 size_t tgcn_cheb_forward_pool_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n, int32_t C, int32_t N,
                                               int32_t layout, int64_t q_chunk, int32_t pool) {
+  if (!S || K < 1 || q < 1 || n < 1 || C < 1 || N < 1 || pool < 1) return 0;
+  // the base figure is 0 for K = 1 on a schedule without partial rows (no hop tensors, no scratch for partial sums): such a layer
+  // still needs the scratch for its output when the shape cannot take the fused epilogue
   const size_t base = tgcn_cheb_forward_workspace_bytes(S, K, q, n, C, layout, q_chunk);
-  if (base == 0 || pool < 1) return 0;
   return align_up(base, 256) + (forward_pool_fusable(K, q, n, C, N, layout, q_chunk, pool) ? 0 : align_up((size_t)q * n * N * sizeof(float), 256));
 }
 
@@ -658,10 +660,15 @@ int tgcn_cheb_forward_pool_f32(void* stream, const tgcn_csr* A, const tgcn_csr_s
   if (pool < 1 || pool > 255 || n % pool != 0 || !out) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pool: pool=%d n=%lld", pool, (long long)n);
   const size_t base = align_up(tgcn_cheb_forward_workspace_bytes(S, K, q, n, C, layout, q_chunk), 256);
   const bool aligned = (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) && (!pool_idx || ((uintptr_t)pool_idx & 3) == 0);
-  if (pool > 1 && aligned && forward_pool_fusable(K, q, n, C, N, layout, q_chunk, pool))       // the (q, n, N) layer output is never written
+  const bool fusable = pool > 1 && forward_pool_fusable(K, q, n, C, N, layout, q_chunk, pool);
+  if (fusable && aligned)       // the (q, n, N) layer output is never written
     return forward_impl(stream, A, S, mode, K, q, n, C, N, x, W, bias, bias_kind, out, layout, q_chunk, workspace, workspace_bytes, pool, pool_idx);
   // other shapes: the layer into scratch, then the relu + pool pass
   const size_t need = base + align_up((size_t)q * n * N * sizeof(float), 256);
+  if (fusable && (!workspace || workspace_bytes < need))
+    // the query sized the workspace for the fused epilogue (it cannot see the pointers): say what is wrong instead of "workspace"
+    TGCN_FAIL(TGCN_ERR_INVALID, "forward_pool: the fused relu + pool epilogue of this shape needs out and bias 16-byte aligned and pool_idx 4-byte aligned "
+                                "(out %p, bias %p, pool_idx %p); align them or pass %zu bytes of workspace for the two-pass form", (void*)out, (const void*)bias, (void*)pool_idx, need);
   if (!workspace || workspace_bytes < need) TGCN_FAIL(TGCN_ERR_WORKSPACE, "forward_pool: workspace %zu < %zu", workspace_bytes, need);
   float* y = (float*)((char*)workspace + base);
   int rc = forward_impl(stream, A, S, mode, K, q, n, C, N, x, W, bias, bias_kind, y, layout, q_chunk, workspace, base, 0, nullptr);
