@@ -277,22 +277,35 @@ def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, r
     bias_local = torch.zeros(sh.owned, spec["g"], device=device)
     g = torch.Generator(device=device).manual_seed(rank)
     x_local = torch.randn((max(q, 1), sh.owned, C_in), device=device, generator=g)[:q]
-    return (lambda overlap=True: sh.forward(x_local, Wf, bias_local, 2, 0, overlap=overlap)), sh, ngroups, q
+    # qs: only the first qs of the group's time steps (the extras size themselves to their budget; columns are independent)
+    return (lambda overlap=True, qs=None: sh.forward(x_local if qs is None else x_local[:qs], Wf, bias_local, 2, 0, overlap=overlap)), sh, ngroups, q
 
 
 def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress=None, out=None):
     """Vertex-sharded and hybrid runs of the same workload (2 timed forwards each), each in two forms: "plain" (one blocking
     exchange per hop, then the hop: the form with the fewest ways to go wrong on a first contact with RCCL) and "overlapped"
     (in-place receives, interior rows and other time steps under the exchange).  They must never cost the headline: every failure
-    becomes an entry with an `error`, entries are appended to `out` as they finish, and if the runs overrun --extras-budget the
-    caller's watchdog prints the headline with the entries finished so far and ends every rank with a non-zero code.
+    becomes an entry with an `error`, entries are appended to `out` as they finish, and every (sharding, form) pair SIZES ITSELF to
+    its share of --extras-budget: one time step is run first (untimed: communicators, buffers), a second one is timed on every
+    rank (max over ranks), and the measured forwards then take as many of the group's time steps as fit the share
+    (`time_steps_used`; time steps are independent columns, so the rate per time step is the same quantity).  Should a run still
+    overrun the whole budget, the caller's watchdog prints the headline with the entries finished so far and ends every rank.
     Every entry carries what each rank exchanges per hop (rows, bytes per channel and peer) and its per-phase times, so a slow or
     wrong run can be diagnosed from the one line."""
     out = [] if out is None else out
     K, H = spec["K"], spec["H"]
     rehearsal = getattr(args, "rehearsal_cpu", False)
     modes = [("vertex", world)] + ([("hybrid", 2)] if world >= 4 and world % 2 == 0 else [])
-    for mode, vs in modes:
+    t_start = time.perf_counter()
+    usable = 0.6 * args.extras_budget               # the rest: shard construction, the phase-log forward's extra syncs, slack
+    n_entries = 2 * len(modes)
+
+    def agree(v, red):
+        t = torch.tensor([v], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=red)
+        return float(t.item())
+
+    for mi, (mode, vs) in enumerate(modes):
         try:
             if progress is not None:
                 progress["mode"] = "%s: building shards" % mode
@@ -303,7 +316,7 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
             sys.stderr.flush()
             out.append(dict(shard=mode, vertex_shards=vs, error="%s: %s" % (type(e).__name__, str(e)[:300])))
             continue
-        for form, overlap in (("plain", False), ("overlapped", True)):
+        for fi, (form, overlap) in enumerate((("plain", False), ("overlapped", True))):
             entry = dict(shard=mode, vertex_shards=vs, form=form)
             if progress is not None:
                 progress["mode"] = "%s / %s" % (mode, form)
@@ -311,26 +324,35 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
                 steps = 2
                 sh.collect_stats = False
                 with torch.no_grad():
-                    fwd(overlap)
+                    fwd(overlap, 1)                         # set-up: communicators, exchange buffers, allocator
                     sync_all()
                     t0 = time.perf_counter()
+                    fwd(overlap, 1)
+                    sync_all()
+                    t1 = agree(time.perf_counter() - t0, dist.ReduceOp.MAX)          # one time step, slowest rank
+                    # this entry's share of what is left of the usable budget, spread over its steps + 1 phase-log forwards;
+                    # every rank computes the same number from the same all-reduced inputs
+                    left = agree(usable - (time.perf_counter() - t_start), dist.ReduceOp.MIN)
+                    share = max(left, 0.0) / max(1, n_entries - (2 * mi + fi))
+                    qs = int(max(1, min(qg, share / ((steps + 1.5) * max(t1, 1e-6)))))
+                    t0 = time.perf_counter()
                     for _ in range(steps):
-                        fwd(overlap)
+                        fwd(overlap, qs)
                     sync_all()
                     dt = time.perf_counter() - t0
                     sh.collect_stats = True                # one more forward with the phase log (device events add their own syncs)
-                    fwd(overlap)
+                    fwd(overlap, qs)
                     sync_all()
                     sh.collect_stats = False
-                tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                dt = float(tmax.item())
+                dt = agree(dt, dist.ReduceOp.MAX)
                 mine = dict(sh.describe(), phases_ms=sh.stats)
                 per_rank = [None] * world
                 dist.all_gather_object(per_rank, mine)
                 C_in = spec["H"] * spec["f"]
-                entry.update(value=round(op.nnz * (K - 1) * q_total * H * steps / dt / 1e9, 3), unit="G edge·timesteps/s", ms_per_step=round(dt / steps * 1e3, 3),
-                             steps=steps, scaling="strong", exchange=sh.exchange, groups=ngroups, time_steps_per_group=qg,
+                # the groups of a hybrid grid run side by side: together they cover ngroups * qs time steps per forward
+                entry.update(value=round(op.nnz * (K - 1) * (qs * ngroups) * H * steps / dt / 1e9, 3), unit="G edge·timesteps/s", ms_per_step=round(dt / steps * 1e3, 3),
+                             steps=steps, scaling="strong", exchange=sh.exchange, groups=ngroups, time_steps_per_group=qg, time_steps_used=qs,
+                             one_time_step_ms=round(t1 * 1e3, 3),
                              message_bytes_per_hop_and_time_step_rank0=mine["bytes_per_channel_in"] * C_in, ranks=per_rank)
             except Exception as e:      # noqa: BLE001 -- reported, never fatal
                 import traceback
@@ -565,15 +587,17 @@ def main():
         extras = []                        # entries finished so far: the watchdog prints them with the headline
 
         def bail():
-            # a stalled exchange (or a GPU hang) in the extras: the headline is still valid, so print it -- marked -- and end every
-            # rank with a non-zero code so that the driver sees from rc that something stalled (plain exit, never a re-exec)
+            # a stalled exchange (or a GPU hang) in the extras: the headline WAS measured, so print it -- marked `extras_abandoned`,
+            # with the entries that finished -- and end every rank with code 0: the extras never decide the exit code of the
+            # scaling run (plain exit, never a re-exec; a rank stuck in a collective cannot be joined, hence os._exit)
             if not printed.acquire(blocking=False):
                 return
             if rank == 0:
                 line["extras_abandoned"] = True
                 line["other_shardings"] = list(extras) + [dict(error="abandoned after %.0f s (--extras-budget)" % args.extras_budget, last_started=progress["mode"])]
                 print(json.dumps(line), flush=True)
-            os._exit(3)
+            sys.stdout.flush()
+            os._exit(0)
         dog = threading.Timer(args.extras_budget, bail)
         dog.daemon = True
         dog.start()

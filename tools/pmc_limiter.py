@@ -16,6 +16,7 @@ import glob
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import time
@@ -81,6 +82,7 @@ def run_pass(counters, out_dir, tag, bench_args, limit):
             k = "hop_fixup_kernel" if "hop_fixup_kernel" in k else "hop_kernel" if "hop_kernel" in k else None
             if k:
                 rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    shutil.rmtree(d, ignore_errors=True)        # raw rocprofv3 output: tens of MB per pass, gpurun merges at most 64 MiB back
     print("pass %s: rc=%d %.0f s, counters %s -> %s" % (tag, rc, time.time() - t0, counters, {k: sorted(v) for k, v in rows.items()}), flush=True)
     return rc, rows
 
