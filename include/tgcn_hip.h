@@ -30,7 +30,7 @@ extern "C" {
 #define TGCN_ERR_WORKSPACE (-3)   /* caller workspace too small */
 #define TGCN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
 
-#define TGCN_ABI_VERSION 4
+#define TGCN_ABI_VERSION 5
 
 /* One stored entry of the sparse operand: 8 bytes, read with a single load. */
 typedef struct tgcn_edge {
@@ -181,6 +181,9 @@ int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* coun
  *                     fp32 MFMA only, 0 vector-ALU one-launch kernels
  *   "small_narrow"    0: C <= 4 inputs use the output-side one-launch kernel (default 1: input-side recursion) */
 int tgcn_set_tuning(const char* key, int32_t value);
+/* Every switch above back to its default (ABI v5).  The switches are process-global developer state: a harness that sets one restores
+ * them with this call in its teardown, whatever happened in between (tests/conftest.py does after every test). */
+void tgcn_reset_tuning(void);
 
 /* Geometry the host needs to build a schedule / size scratch for a row length C (floats).
  * `aligned16` != 0 when every operand base, row stride and batch stride is a multiple of 4 floats. */

@@ -42,3 +42,12 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _tuning_back_to_defaults():
+    """tgcn_set_tuning switches are process-global: whatever a test set (and however it ended) is undone before the next test runs."""
+    yield
+    from tgcn_amd import _lib
+    if _lib.loaded():
+        _lib.lib().tgcn_reset_tuning()

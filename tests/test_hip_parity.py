@@ -281,23 +281,25 @@ def test_project_vs_numpy(M, Kc, N, T, inter, variant, gpu_device):
     kernel where the weight fits in LDS; 5: the vector-ALU kernel for narrow contractions (sum of Kc <= 16) wherever it
     applies (variant 0 picks it from M >= 4096)."""
     from tgcn_amd import functional as F, _lib
-    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", variant))
     rng = np.random.default_rng(M + Kc)
     terms = [rng.standard_normal((M, Kc)).astype(np.float32) for _ in range(T)]
     W = (rng.standard_normal((T, Kc, N)) / np.sqrt(T * Kc)).astype(np.float32)
     nv = M // inter
-    for kind, bias in ((0, None), (1, rng.standard_normal(N).astype(np.float32)),
-                       (2, rng.standard_normal((nv, N)).astype(np.float32))):
-        ref = sum(t.astype(np.float64) @ w.astype(np.float64) for t, w in zip(terms, W))
-        if inter > 1:      # m = i*inter + q  ->  row q*nv + i
-            ref = ref.reshape(nv, inter, N).transpose(1, 0, 2).reshape(M, N)
-        if kind == 1:
-            ref = ref + bias
-        elif kind == 2:
-            ref = (ref.reshape(-1, nv, N) + bias).reshape(M, N)
-        out = F.cheb_project([_dev(t) for t in terms], _dev(W), None if bias is None else _dev(bias), kind, nv, inter)
-        assert rel_err(out.cpu().numpy(), ref) <= TOL
-    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 0))
+    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", variant))
+    try:
+        for kind, bias in ((0, None), (1, rng.standard_normal(N).astype(np.float32)),
+                           (2, rng.standard_normal((nv, N)).astype(np.float32))):
+            ref = sum(t.astype(np.float64) @ w.astype(np.float64) for t, w in zip(terms, W))
+            if inter > 1:      # m = i*inter + q  ->  row q*nv + i
+                ref = ref.reshape(nv, inter, N).transpose(1, 0, 2).reshape(M, N)
+            if kind == 1:
+                ref = ref + bias
+            elif kind == 2:
+                ref = (ref.reshape(-1, nv, N) + bias).reshape(M, N)
+            out = F.cheb_project([_dev(t) for t in terms], _dev(W), None if bias is None else _dev(bias), kind, nv, inter)
+            assert rel_err(out.cpu().numpy(), ref) <= TOL
+    finally:          # (tests/conftest.py resets every switch after each test as well)
+        _lib.lib().tgcn_reset_tuning()
 
 
 @pytest.mark.parametrize("M,Kc,N,T", [(1000, 64, 64, 5), (5003, 28, 64, 3), (333, 7, 5, 2), (4096, 100, 70, 2), (50, 1, 8, 6), (9000, 12, 15, 33)])

@@ -54,6 +54,7 @@ SIGNATURES = {
     "tgcn_profile_start": (C.c_int, [C.c_int32]),
     "tgcn_profile_stop": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "tgcn_set_tuning": (C.c_int, [C.c_char_p, C.c_int32]),
+    "tgcn_reset_tuning": (None, []),
     "tgcn_hop_vec_width": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_lanes_per_row": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_groups_per_block": (C.c_int, [C.c_int32, C.c_int]),
@@ -112,7 +113,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4      # include/tgcn_hip.h: TGCN_ABI_VERSION
+ABI_VERSION = 5      # include/tgcn_hip.h: TGCN_ABI_VERSION
 
 
 def source_hash():
@@ -177,6 +178,11 @@ def lib():
             raise TgcnError("tgcn_amd: ABI version mismatch")
         _lib = handle
     return _lib
+
+
+def loaded():
+    """True once lib() has mapped the library (test teardown resets the tuning switches only then)."""
+    return _lib is not None
 
 
 def check(rc):

@@ -51,6 +51,12 @@ extern "C" {
 const char* tgcn_last_error(void) { return g_err; }
 int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
+void tgcn_reset_tuning(void) {
+  g_hop_variant.store(0); g_hop_remap.store(1); g_hop_seg_remap.store(0); g_hop_mix.store(0); g_hop_stream.store(1); g_hop_lds_pad.store(0);
+  g_proj_variant.store(0); g_small_dense.store(2); g_small_narrow.store(1); g_x3_form.store(2); g_compact_proj.store(0); g_x3_tail.store(1);
+  g_overlap.store(0);
+}
+
 int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "hop_variant") == 0) { g_hop_variant.store(value); return TGCN_OK; }
   if (key && strcmp(key, "hop_xcd_remap") == 0) { g_hop_remap.store(value != 0); return TGCN_OK; }
@@ -171,18 +177,57 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
                         int32_t win_n, int32_t win_t, int32_t bias_cols = -1, const int32_t* rowmap = nullptr, uint32_t mapped = 0,
                         int32_t nbatch = 1, const int64_t* a_bs = nullptr, int64_t out_bs = 0, int32_t pool = 0, uint8_t* pool_idx = nullptr);
 
-// Whether project_impl's dispatch (below) lands on a kernel with the fused relu + pool epilogue for this shape: the W-resident
-// exact kernel or project_x3_kernel with at most 4 column tiles, both through their vector epilogue.  Keep in step with the
-// dispatch in project_impl.
+// THE dispatch of the projection: which kernel a shape takes.  project_impl launches what this returns and project_pool_fusable asks the
+// same function, so the fused relu + pool epilogue can never be requested from a kernel that does not have it.
+// project_variant: 0 auto (vector-ALU kernel for a few scalars per row, bf16x3 on large problems, else exact fp32: W-resident when the
+// weight fits, streaming otherwise), 1 exact-fp32 streaming, 2 exact-fp32 (W-resident with 16-row wave tiles when it fits), 3 bf16x3 always,
+// 4 exact fp32 auto, 5 vector-ALU kernel whenever it applies.
+enum ProjKernel { kProjNarrow, kProjResident, kProjX3, kProjX3Wide, kProjStream };
+struct ProjChoice {
+  ProjKernel kernel;
+  int nt;            // 16-column tiles per workgroup of the W-resident kernel
+  int nts;           // 16-column tiles per workgroup of the streaming / bf16x3 kernels
+  size_t wbytes;     // LDS image of the weight for the W-resident kernel
+  bool pool_epilogue;   // the kernel can end in relu + max over consecutive rows (through its vector epilogue)
+};
+static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterms, bool vec4, bool vec_epilogue, bool has_rowmap, bool windows) {
+  ProjChoice c;
+  const int pv = g_proj_variant.load();
+  c.nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
+  c.wbytes = (size_t)nterms * ((Kc + 3) / 4 * 4) * c.nt * 16 * sizeof(float);
+  // streaming-W / bf16x3 kernels: widest column tile that keeps padding low, so A is read once per block and no MFMA works
+  // on padding (N = 160 -> one block of 10 tiles instead of three of 4)
+  const int tiles = (N + 15) / 16;
+  c.nts = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : tiles <= 6 ? 6 : tiles <= 8 ? 8 : 10;
+  if (tiles > 10) {   // several column blocks: the width with the least padded tiles
+    int best = 10, waste = (10 - tiles % 10) % 10;
+    for (int w : {8, 6, 4}) { const int ws = (w - tiles % w) % w; if (ws < waste) { waste = ws; best = w; } }
+    c.nts = best;
+  }
+  c.pool_epilogue = false;
+  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && !windows && !has_rowmap && vec_epilogue && N <= 1024 && (M >= 4096 || pv == 5)) {
+    c.kernel = kProjNarrow;           // a few scalars per row: the output streams from the vector ALU
+    return c;
+  }
+  const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
+  if (c.wbytes <= (size_t)kResMaxWBytes && pv != 1 && !use_x3) {
+    c.kernel = kProjResident;
+    c.pool_epilogue = vec_epilogue;
+    return c;
+  }
+  if (use_x3) {
+    c.kernel = (vec4 && c.nts >= 6 && g_x3_form.load() == 2) ? kProjX3Wide : kProjX3;      // wide outputs: A fragments from registers
+    c.pool_epilogue = c.kernel == kProjX3 && c.nts <= 4 && vec_epilogue;
+    return c;
+  }
+  c.kernel = kProjStream;
+  return c;
+}
+
+// Whether the projection of this shape (aligned operands, no row map) ends in a kernel with the fused relu + pool epilogue.
 static bool project_pool_fusable(int64_t M, int32_t Kc, int32_t N, int32_t nterms, int32_t pool) {
   if (pool < 2 || 16 % pool != 0 || M % pool != 0 || N % 4 != 0 || nterms > kMaxTerms) return false;
-  const int pv = g_proj_variant.load();
-  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && N <= 1024 && (M >= 4096 || pv == 5)) return false;   // narrow kernel
-  const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
-  const int nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
-  const size_t wbytes = (size_t)nterms * ((Kc + 3) / 4 * 4) * nt * 16 * sizeof(float);
-  if (wbytes <= (size_t)kResMaxWBytes && pv != 1 && !use_x3) return true;                                                  // resident
-  return use_x3 && (N + 15) / 16 <= 4;                                                                                      // x3, NT <= 4
+  return project_choose(M, Kc, N, nterms, Kc % 4 == 0, true, false, false).pool_epilogue;
 }
 
 int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
@@ -230,19 +275,16 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.bias_kind = bias_kind; p.accumulate = accumulate;
   p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
                    (p.bias_cols % 4 == 0);
-  if (pool > 1) {     // fused relu + max-pool epilogue: only where the dispatch below takes a kernel that has it
-    if (rowmap || interleave != 1 || accumulate || win_n != 0 || nbatch != 1 || !p.vec_epilogue || !project_pool_fusable(M, Kc, N, nterms, pool))
+  const ProjChoice choice = project_choose(M, Kc, N, nterms, vec4, p.vec_epilogue != 0, rowmap != nullptr, win_n != 0);
+  if (pool > 1) {     // fused relu + max-pool epilogue: only where the dispatch takes a kernel that has it
+    if (rowmap || interleave != 1 || accumulate || win_n != 0 || nbatch != 1 || pool < 2 || 16 % pool != 0 || M % pool != 0 || !choice.pool_epilogue)
       TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: no fused pool epilogue for this shape (M=%lld Kc=%d N=%d terms=%d pool=%d)", (long long)M, Kc, N, nterms, pool);
     p.pool = pool; p.pool_idx = pool_idx;
   }
   p.nbatch = 1;
   if (nbatch > 1) {
-    // samples sharing the tile rows: inside project_x3_kernel<NT, true> (bias tile kept in registers), a host loop otherwise
-    const int pv0 = g_proj_variant.load();
-    const bool x3 = pv0 == 3 || (pv0 == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
-    const bool narrow = (pv0 == 0 || pv0 == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && win_n == 0 && !rowmap && p.vec_epilogue && N <= 1024 && (M >= 4096 || pv0 == 5);
-    const bool v2 = (N + 15) / 16 > 4 && g_x3_form.load() == 2;      // project_x3v2_kernel takes the wide outputs
-    if (x3 && vec4 && !narrow && !v2) {
+    // samples sharing the tile rows: inside project_x3_kernel<NT, true>, a host loop otherwise
+    if (choice.kernel == kProjX3 && vec4) {
       p.nbatch = nbatch; p.out_bs = out_bs;
       for (int t = 0; t < nterms; ++t) {
         p.a_bs[t] = a_bs[t];
@@ -260,17 +302,12 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
       return TGCN_OK;
     }
   }
-  const int nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
+  const int nt = choice.nt;
   hipStream_t st = (hipStream_t)stream;
   const int kc4 = (Kc + 3) / 4 * 4;
-  const size_t wbytes = (size_t)nterms * kc4 * nt * 16 * sizeof(float);
+  const size_t wbytes = choice.wbytes;
   const unsigned gy = (unsigned)((N + nt * 16 - 1) / (nt * 16));
-  // project_variant: 0 auto (bf16x3 on large problems, else exact fp32: W-resident when it fits, streaming otherwise),
-  // 1 exact-fp32 streaming, 2 exact-fp32 (W-resident with 16-row wave tiles when it fits), 3 bf16x3 always, 4 exact fp32 auto,
-  // 5 vector-ALU kernel whenever it applies (auto uses it for sum(Kc) <= 16 and M >= 4096)
-  const int pv = g_proj_variant.load();
-  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && win_n == 0 && !rowmap && p.vec_epilogue && N <= 1024 &&
-      (M >= 4096 || pv == 5)) {
+  if (choice.kernel == kProjNarrow) {
     // a few scalars per row: stream the output from the vector ALU (project_narrow_kernel)
     const int L = N / 4, RP = kBlock / L;
     const int ktot = Kc * nterms;
@@ -286,8 +323,8 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (narrow)");
     return TGCN_OK;
   }
-  const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
-  if (wbytes <= (size_t)kResMaxWBytes && pv != 1 && !use_x3) {
+  const bool use_x3 = choice.kernel == kProjX3 || choice.kernel == kProjX3Wide;
+  if (choice.kernel == kProjResident) {
     const int rt = g_proj_variant.load() == 2 ? 1 : 2;                  // 8 waves x 32 rows (variant 2: 16 waves x 16 rows)
     const int res_rows = 16 * rt, res_waves = 1024 / rt / 64;
     const size_t lds = wbytes + (size_t)kResScratchFloats * sizeof(float);
@@ -312,15 +349,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   }
   const int64_t mb = (M + 127) / 128;
   if (mb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
-  // streaming-W kernel: widest column tile that keeps padding low, so A is read once per block and no MFMA works
-  // on padding (N = 160 -> one block of 10 tiles instead of three of 4)
-  const int tiles = (N + 15) / 16;
-  int nts = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : tiles <= 6 ? 6 : tiles <= 8 ? 8 : 10;
-  if (tiles > 10) {   // several column blocks: the width with the least padded tiles
-    int best = 10, waste = (10 - tiles % 10) % 10;
-    for (int c : {8, 6, 4}) { const int w = (c - tiles % c) % c; if (w < waste) { waste = w; best = c; } }
-    nts = best;
-  }
+  const int tiles = (N + 15) / 16, nts = choice.nts;
   const dim3 grid((unsigned)mb, (unsigned)((tiles + nts - 1) / nts));
   ProfScope ps(TGCN_PROF_PROJECT, st);
 #define TGCN_PROJ(NTV)                                                                               \
@@ -340,7 +369,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     }
     const dim3 grid3v2((unsigned)(main_blocks + tail_blocks), grid.y);
 #define TGCN_PROJ3(NTV)                                                                              \
-  if (vec4 && NTV >= 6 && g_x3_form.load() == 2) hipLaunchKernelGGL((project_x3v2_kernel<NTV>), grid3v2, dim3(512), 0, st, p, (int)main_blocks); /* wide outputs: compute-bound */ \
+  if (NTV >= 6 && choice.kernel == kProjX3Wide) hipLaunchKernelGGL((project_x3v2_kernel<NTV>), grid3v2, dim3(512), 0, st, p, (int)main_blocks); /* wide outputs: compute-bound */ \
   else if (vec4) hipLaunchKernelGGL((project_x3_kernel<NTV, true>), grid3, dim3(512), 0, st, p);      \
   else hipLaunchKernelGGL((project_x3_kernel<NTV, false>), grid3, dim3(512), 0, st, p);
     switch (nts) {
