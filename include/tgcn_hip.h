@@ -136,6 +136,25 @@ size_t tgcn_csr_build_workspace_bytes(int64_t n, int64_t nnz);
 int tgcn_csr_build_f32(void* stream, int64_t n, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col, const float* val,
                        int32_t* rowptr, tgcn_edge* edges, void* workspace, size_t workspace_bytes);
 
+/* ABI v5 -- the operand VALUES the callers compute before their layers, on caller memory (device pointers, `stream`), so that a host side
+ * that owns its arrays (tgcn_amd/graph.py) has no arithmetic of its own: one builder, the library's.  Both synchronise the stream once
+ * (range flag / count) and write a HOST count; workspace 256-byte aligned.
+ *   tgcn_edge_normalise_f32       edge list (2, E) int64 [+ weights, nullable] -> COO of the ChebConv / ChebTimeConv operand
+ *                                 (tgcn/nn/gcn.py:398-413 == :495-510): self loops removed, lap_e = -deg^-1/2[row] * w_e * deg^-1/2[col] with
+ *                                 deg = UNWEIGHTED edge count per source vertex (integer atomics: order-independent), deg^-1/2 = 0 at degree 0.
+ *                                 row / col / val: E slots; *kept entries are written, in the given order.  (tgcn_graph_create_from_edge_index
+ *                                 is this followed by tgcn_graph_create_from_coo.)
+ *   tgcn_adjacency_normalise_f32  COO of the weight matrix W (m entries, any order) -> COO of rescale_L(laplacian(W, normalized=True), lmax)
+ *                                 (gcn/graph.py:117-136, 232-238): d = colsum(W) + eps -- a stable sort by column, then one wave per column in a
+ *                                 fixed summation order, no float atomics --, L-hat = (2/lmax) (I - D^-1/2 W D^-1/2) - I.  row_out / col_out /
+ *                                 val_out: m + n slots; *count = m, plus n diagonal entries when lmax != 2. */
+size_t tgcn_edge_normalise_workspace_bytes(int64_t n, int64_t E);
+int tgcn_edge_normalise_f32(void* stream, int64_t n, int64_t E, const int64_t* edge_index, const float* edge_weight, int64_t* row, int64_t* col,
+                            float* val, int64_t* kept, void* workspace, size_t workspace_bytes);
+size_t tgcn_adjacency_normalise_workspace_bytes(int64_t n, int64_t m);
+int tgcn_adjacency_normalise_f32(void* stream, int64_t n, int64_t m, const int64_t* row, const int64_t* col, const float* weight, float lmax,
+                                 int64_t* row_out, int64_t* col_out, float* val_out, int64_t* count, void* workspace, size_t workspace_bytes);
+
 /* One level of the reference's Graclus / METIS-style coarsening (gcn/coarsening.py:119-165: a Python loop over vertices and
  * entries) as host code: HOST arrays in and out -- coarsening is one-off preprocessing of the caller's graph (tgcn_amd/
  * coarsening.py mirrors coarsen / metis / compute_perm / perm_data / perm_adjacency around it).  Entries sorted by row;

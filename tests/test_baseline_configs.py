@@ -122,3 +122,37 @@ def test_cfg5_reduced_rmat_tgcncheb(labeling, gpu_device):
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn((3, n, 64), device="cuda", generator=g)
     _check(layer, op, x, 2, q_check=2)
+
+
+def test_cfg5_full_size_one_time_step(gpu_device):
+    """configs[4] AT FULL SIZE -- the workload BENCH times: R-MAT 10 M vertices / 160 M entries (random labels), TGCNCheb(L, 64, 64, K=5)
+    -- one of its 16 time steps through the module, against oracle/cheb_ref.c (about 12 s on the box's host cores).  Asserts that it is
+    the compacted path (5.27 M structurally empty rows -> compact hop tensors, row-mapped projections) with hop outputs beyond the
+    Infinity Cache, i.e. the streaming form of hop_kernel with whole-row wave segments, lane-group segments and the fix-up: what
+    bench.py's own check covers, under pytest.  (> 2^31-element offsets: tests/test_compact_wave.py::test_offsets_beyond_2_31_elements.)"""
+    import tgcn_amd
+    from tgcn_amd import functional as F
+    from tools import synth
+    n, nnz = 10_000_000, 160_000_000
+    _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling="random", device=gpu_device)
+    op = tgcn_amd.GraphOperand.from_coo(n, row, col, val, gpu_device)
+    del row, col, val
+    assert op.nnz == nnz
+    plan = op.compact_plan()
+    assert plan is not None and plan.n_empty > 5_000_000 and plan.n_c + plan.n_empty == n
+    assert F.COMPACT and F.choose_layout(1, n, 64) == 0                      # layer_forward takes cheb_forward_compact for this shape
+    assert plan.n_c * 64 * 4 > (256 << 20)                                   # a hop's output exceeds the Infinity Cache: tgcn_csr_hop_f32 streams
+    sched = plan.schedule_for(64, True)
+    assert sched.nwseg > 0 and sched.nseg > sched.nwseg and sched.nlong > 0 and sched.nhuge > 0 and sched.npartial > 0
+    torch.manual_seed(1)
+    layer = tgcn_amd.TGCNCheb(op, 64, 64, 5).cuda()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn((1, n, 64), device="cuda", generator=g)
+    calls = []
+    real = F.cheb_forward_compact
+    F.cheb_forward_compact = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        _check(layer, op, x, 2)
+    finally:
+        F.cheb_forward_compact = real
+    assert calls, "the module forward did not take the compacted driver"

@@ -109,3 +109,56 @@ def test_library_graph_entry_points_from_csr_and_edge_index(gpu_device):
     a, b = got_e[:, 1].contiguous().view(torch.float32), ref.edges[: csr.nnz, 1].contiguous().view(torch.float32)
     assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())       # rsqrt forms differ in the last bit (1/sqrtf vs pow(-0.5))
     L.tgcn_graph_destroy(g)
+
+
+@pytest.mark.parametrize("n,E,weighted", [(1, 0, False), (5, 9, True), (3000, 40_000, False), (3000, 40_000, True), (200_000, 3_000_000, True), (50, 5000, True)])
+def test_edge_list_operand_by_the_library_equals_torch_builder(n, E, weighted, gpu_device, monkeypatch):
+    """GraphOperand.from_edge_index on the product path = tgcn_edge_normalise_f32 + tgcn_csr_build_f32 (one builder).
+    Against the torch index-op form kept as the cross-check: same entries in the same order (self loops, duplicates, vertices without
+    outgoing edges, weights); the values agree to the last bit (integer degrees, 1/sqrtf and two multiplies on both sides)."""
+    from tgcn_amd import graph
+    rng = np.random.default_rng(n + E)
+    ei = torch.as_tensor(rng.integers(0, n, (2, E))).cuda()
+    if E > 10:
+        ei[1, : E // 10] = ei[0, : E // 10]                         # self loops
+        ei[0, E // 2:] = ei[0, E // 2:] % max(1, n // 2)            # the upper half of the vertices mostly without outgoing edges
+    w = torch.as_tensor(rng.uniform(0.1, 2.0, E).astype(np.float32)).cuda() if weighted else None
+    monkeypatch.setattr(graph, "BUILDER", "library")
+    a = graph.GraphOperand.from_edge_index(ei, w, n)
+    monkeypatch.setattr(graph, "BUILDER", "torch")
+    b = graph.GraphOperand.from_edge_index(ei, w, n)
+    assert a.nnz == b.nnz and torch.equal(a.rowptr, b.rowptr)
+    assert torch.equal(a.edges[: a.nnz, 0], b.edges[: b.nnz, 0])
+    va, vb = a.edges[: a.nnz, 1].contiguous().view(torch.float32), b.edges[: b.nnz, 1].contiguous().view(torch.float32)
+    assert torch.allclose(va, vb, rtol=2e-7, atol=0)
+
+
+def test_edge_list_operand_rejects_bad_input(gpu_device):
+    from tgcn_amd import graph, _lib
+    with pytest.raises(_lib.TgcnError, match="vertex index outside"):
+        graph.GraphOperand.from_edge_index(torch.tensor([[0, 1, 7], [1, 2, 0]], device="cuda"), None, 3)
+    with pytest.raises(_lib.TgcnError, match="requires_grad"):
+        graph.GraphOperand.from_edge_index(torch.tensor([[0, 1], [1, 2]], device="cuda"), torch.ones(2, device="cuda", requires_grad=True), 3)
+
+
+@pytest.mark.parametrize("n,m,lmax", [(1, 0, 2.0), (40, 300, 2.0), (40, 300, 1.3), (5000, 80_000, 2.0), (300_000, 4_000_000, 1.7), (7, 50_000, 2.0)])
+def test_adjacency_operand_by_the_library_equals_torch_builder(n, m, lmax, gpu_device, monkeypatch):
+    """GraphOperand.from_adjacency on the product path = tgcn_adjacency_normalise_f32 (stable sort by column, one wave per column in a fixed
+    order, values, diagonal) + tgcn_csr_build_f32, against the torch form (index_add_: float atomics) and bitwise against itself."""
+    from tgcn_amd import graph
+    rng = np.random.default_rng(n + m)
+    row = torch.as_tensor(rng.integers(0, n, m)).cuda()
+    col = torch.as_tensor(rng.integers(0, n, m)).cuda()
+    if m > 1000:
+        col[: m // 4] = col[: m // 4] % 3                           # hub columns: thousands of terms in one column sum
+    w = torch.as_tensor(rng.uniform(0.1, 2.0, m).astype(np.float32)).cuda()
+    monkeypatch.setattr(graph, "BUILDER", "library")
+    a = graph.GraphOperand.from_adjacency(n, row, col, w, lmax=lmax)
+    a2 = graph.GraphOperand.from_adjacency(n, row, col, w, lmax=lmax)
+    monkeypatch.setattr(graph, "BUILDER", "torch")
+    b = graph.GraphOperand.from_adjacency(n, row, col, w, lmax=lmax)
+    assert a.nnz == b.nnz == m + (n if lmax != 2.0 else 0) and torch.equal(a.rowptr, b.rowptr)
+    assert torch.equal(a.edges[: a.nnz], a2.edges[: a.nnz])          # deterministic: no float atomics
+    assert torch.equal(a.edges[: a.nnz, 0], b.edges[: b.nnz, 0])
+    va, vb = a.edges[: a.nnz, 1].contiguous().view(torch.float32), b.edges[: b.nnz, 1].contiguous().view(torch.float32)
+    assert torch.allclose(va, vb, rtol=1e-5, atol=1e-30)             # column sums of thousands of terms in another order

@@ -303,6 +303,36 @@ def test_modules_survive_deepcopy_and_pickle():
     assert conv.weight.shape == (4, 2, 3)
 
 
+def test_operand_cache_evicts_least_recently_used_only():
+    """past 16 entries the cache used to drop everything; a training loop that swaps edge_index per subject
+    (examples/pytorch_geo_based/pygeo_hcp.py:284) must keep the operands it keeps coming back to."""
+    from tgcn_amd.nn import _OperandCache
+    cache = _OperandCache()
+    built = []
+    mk = lambda k: (lambda: built.append(k) or ("op", k))
+    for k in range(16):
+        cache.get(k, mk(k))
+    assert cache.get(0, mk(0)) == ("op", 0) and built == list(range(16))      # hit: entry 0 is now the most recent
+    cache.get(16, mk(16))                                                     # evicts entry 1, the least recently used
+    assert len(cache._d) == 16 and 0 in cache._d and 1 not in cache._d and 16 in cache._d
+    cache.get(1, mk(1))
+    assert built == list(range(17)) + [1] and 2 not in cache._d
+
+
+def test_learnable_operand_values_are_refused_not_ignored():
+    """Reference: lap = -deg[row] * edge_weight * deg[col] and spmm's `value` are differentiable (tgcn/nn/gcn.py:413,510,296-308); here the
+    operand is packed outside autograd, so a weight that requires grad raises instead of silently getting no gradient."""
+    import tgcn_amd
+    from tgcn_amd import _lib
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]])
+    w = torch.ones(3, requires_grad=True)
+    with pytest.raises(_lib.TgcnError, match="requires_grad"):
+        tgcn_amd.GraphOperand.from_edge_index(ei, w, 3)
+    with pytest.raises(_lib.TgcnError, match="requires_grad"):
+        tgcn_amd.spmm(ei, w, 3, torch.ones(3, 2))
+    assert tgcn_amd.GraphOperand.from_edge_index(ei, w.detach(), 3).nnz == 3      # detached weights build (CPU tensors: the torch form)
+
+
 def test_operand_cache_is_thread_safe():
     """nn.DataParallel runs replica forwards in threads that share the module's operand cache (and the fold-matrix cache):
     concurrent first uses must build each entry once and hand every thread the same object."""

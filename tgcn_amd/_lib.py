@@ -55,6 +55,10 @@ SIGNATURES = {
     "tgcn_profile_stop": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "tgcn_set_tuning": (C.c_int, [C.c_char_p, C.c_int32]),
     "tgcn_reset_tuning": (None, []),
+    "tgcn_edge_normalise_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "tgcn_edge_normalise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_int64), _P, C.c_size_t]),
+    "tgcn_adjacency_normalise_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "tgcn_adjacency_normalise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, _P, C.POINTER(C.c_int64), _P, C.c_size_t]),
     "tgcn_hop_vec_width": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_lanes_per_row": (C.c_int, [C.c_int32, C.c_int]),
     "tgcn_hop_groups_per_block": (C.c_int, [C.c_int32, C.c_int]),

@@ -305,6 +305,135 @@ __global__ void edge_normalise_kernel(const int64_t* __restrict__ row, const int
   }
 }
 
+inline size_t edge_norm_ws_bytes(int64_t n, int64_t E) {
+  const size_t m1 = (size_t)(E > 0 ? E : 1) + 1;
+  return align_up(m1 * 8, 256) * 2 + align_up(scan_ws_elems(E + 1) * 8, 256) + align_up((size_t)n * 4, 256) + 256;
+}
+
+// Edge list (2, E) [+ weights] -> COO of the ChebConv / ChebTimeConv operand in caller memory (row / col / val hold up to E entries),
+// in the given order; *kept_host = entries written.  Two read-backs (range flag, count).  ws: edge_norm_ws_bytes(n, E).
+inline int edge_normalise_device(hipStream_t st, int64_t n, int64_t E, const int64_t* ei, const float* w, int64_t* row, int64_t* col,
+                                 float* val, int64_t* kept_host, char* ws) {
+  const size_t m1 = (size_t)(E > 0 ? E : 1) + 1;
+  int64_t* keep = (int64_t*)ws; ws += align_up(m1 * 8, 256);
+  int64_t* pos = (int64_t*)ws; ws += align_up(m1 * 8, 256);
+  int64_t* scanws = (int64_t*)ws; ws += align_up(scan_ws_elems(E + 1) * 8, 256);
+  unsigned int* deg = (unsigned int*)ws; ws += align_up((size_t)n * 4, 256);
+  int* bad = (int*)ws;
+  *kept_host = 0;
+  if (E <= 0) return TGCN_OK;
+  if (hipMemsetAsync(keep, 0, m1 * 8, st) != hipSuccess || hipMemsetAsync(deg, 0, (size_t)n * 4, st) != hipSuccess ||
+      hipMemsetAsync(bad, 0, sizeof(int), st) != hipSuccess)
+    TGCN_FAIL(TGCN_ERR_LAUNCH, "edge_normalise: memset failed");
+  hipLaunchKernelGGL(edge_keep_kernel, dim3(grid_1d(E)), dim3(kBlock), 0, st, ei, E, n, keep, bad);
+  scan_i64(st, keep, pos, E + 1, 0, scanws);                                    // pos[E] = number of kept edges
+  int h_bad = 0;
+  int64_t kept = 0;
+  if (hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(&kept, pos + E, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    TGCN_FAIL(TGCN_ERR_LAUNCH, "edge_normalise: device read failed");
+  if (h_bad) TGCN_FAIL(TGCN_ERR_INVALID, "edge list: vertex index outside [0, %lld)", (long long)n);
+  hipLaunchKernelGGL(edge_compact_kernel, dim3(grid_1d(E)), dim3(kBlock), 0, st, ei, w, E, (const int64_t*)keep, (const int64_t*)pos, row, col, val, deg);
+  if (kept > 0)
+    hipLaunchKernelGGL(edge_normalise_kernel, dim3(grid_1d(kept)), dim3(kBlock), 0, st, (const int64_t*)row, (const int64_t*)col, val, (const unsigned int*)deg, kept);
+  TGCN_CHECK_LAUNCH("edge_normalise");
+  *kept_host = kept;
+  return TGCN_OK;
+}
+
+// --------------------------------------------------------------------------------------------------
+// adjacency COO -> rescale_L(laplacian(W, normalized=True), lmax) COO (gcn/graph.py:117-136, 232-238): device kernels
+// --------------------------------------------------------------------------------------------------
+__global__ void range_check_kernel(const int64_t* __restrict__ v, int64_t m, int64_t limit, int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x)
+    if (v[i] < 0 || v[i] >= limit) *bad = 1;
+}
+
+// cptr[j] = first position of the sorted key array holding a key >= j (j = 0 .. n): column j's entries are [cptr[j], cptr[j+1])
+__global__ void lower_bound_kernel(const uint32_t* __restrict__ keys, int64_t m, int64_t n, int64_t* __restrict__ cptr) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= n; j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = m;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)keys[mid] < j) lo = mid + 1; else hi = mid; }
+    cptr[j] = lo;
+  }
+}
+
+// dis[j] = 1 / sqrt(sum of the weights of column j + eps): one wave per column, lanes take the column's entries (in their given order)
+// with stride 64 and fold through a fixed shuffle tree -- no float atomics, the same bits every run
+__global__ __launch_bounds__(kBlock) void colsum_rsqrt_kernel(const float* __restrict__ w, const uint32_t* __restrict__ order,
+                                                              const int64_t* __restrict__ cptr, int64_t n, float eps, float* __restrict__ dis) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); j < n; j += nwaves) {
+    float acc = 0.f;
+    for (int64_t k = cptr[j] + lane; k < cptr[j + 1]; k += 64) acc += w[order[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) dis[j] = 1.0f / sqrtf(acc + eps);
+  }
+}
+
+// entry e < m: {row, col, -scale * dis[row] * w * dis[col]}; entry m + i (diagonal, only when scale != 1): {i, i, scale - 1}
+__global__ void lap_values_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col, const float* __restrict__ w, int64_t m, int64_t n,
+                                  const float* __restrict__ dis, float scale, int diag, int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
+                                  float* __restrict__ val_out) {
+  const int64_t total = m + (diag ? n : 0);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < m) {
+      const int64_t r = row[e], c = col[e];
+      row_out[e] = r; col_out[e] = c;
+      val_out[e] = -scale * dis[r] * w[e] * dis[c];
+    } else {
+      row_out[e] = col_out[e] = e - m;
+      val_out[e] = scale - 1.0f;
+    }
+  }
+}
+
+inline size_t adjacency_norm_ws_bytes(int64_t n, int64_t m) {
+  const size_t m1 = (size_t)(m > 0 ? m : 1);
+  return align_up(m1 * 4, 256) * 2 + sort_ws_bytes(m) + align_up((size_t)(n + 2) * 8, 256) + align_up((size_t)n * 4, 256) + 256;
+}
+
+// COO of the weight matrix W (m entries, any order) -> COO of L-hat = (2/lmax) (I - D^-1/2 W D^-1/2) - I, d = colsum(W) + eps, in caller
+// memory (m + n slots; the n diagonal entries are written only when lmax != 2).  One read-back (range flag).  ws: adjacency_norm_ws_bytes.
+inline int adjacency_normalise_device(hipStream_t st, int64_t n, int64_t m, const int64_t* row, const int64_t* col, const float* w, float lmax,
+                                      int64_t* row_out, int64_t* col_out, float* val_out, int64_t* count_host, char* ws) {
+  const size_t m1 = (size_t)(m > 0 ? m : 1);
+  uint32_t* keys = (uint32_t*)ws; ws += align_up(m1 * 4, 256);
+  uint32_t* order = (uint32_t*)ws; ws += align_up(m1 * 4, 256);
+  char* sort_ws = ws; ws += sort_ws_bytes(m);
+  int64_t* cptr = (int64_t*)ws; ws += align_up((size_t)(n + 2) * 8, 256);
+  float* dis = (float*)ws; ws += align_up((size_t)n * 4, 256);
+  int* bad = (int*)ws;
+  const float scale = 2.0f / lmax;
+  const int diag = scale != 1.0f;
+  *count_host = 0;
+  if (hipMemsetAsync(bad, 0, sizeof(int), st) != hipSuccess) TGCN_FAIL(TGCN_ERR_LAUNCH, "adjacency_normalise: memset failed");
+  if (m > 0) {
+    const unsigned g = grid_1d(m);
+    hipLaunchKernelGGL(range_check_kernel, dim3(g), dim3(kBlock), 0, st, row, m, n, bad);
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kBlock), 0, st, order, m);
+    hipLaunchKernelGGL(gather_key_kernel, dim3(g), dim3(kBlock), 0, st, col, (const uint32_t*)nullptr, keys, m, n, bad);
+    int h_bad = 0;
+    if (hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      TGCN_FAIL(TGCN_ERR_LAUNCH, "adjacency_normalise: device read failed");
+    if (h_bad) TGCN_FAIL(TGCN_ERR_INVALID, "adjacency: vertex index outside [0, %lld)", (long long)n);
+    radix_sort_pairs(st, keys, order, m, bits_for(n), sort_ws);                  // stable: a column's entries keep their given order
+  }
+  hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_1d(n + 1)), dim3(kBlock), 0, st, (const uint32_t*)keys, m, n, cptr);
+  int64_t cblocks = (n + kBlock / 64 - 1) / (kBlock / 64);
+  if (cblocks > 65536) cblocks = 65536;
+  hipLaunchKernelGGL(colsum_rsqrt_kernel, dim3((unsigned)cblocks), dim3(kBlock), 0, st, w, (const uint32_t*)order, (const int64_t*)cptr, n,
+                     1.401298464324817e-45f /* np.spacing(float32(0)) */, dis);
+  const int64_t total = m + (diag ? n : 0);
+  if (total > 0)
+    hipLaunchKernelGGL(lap_values_kernel, dim3(grid_1d(total)), dim3(kBlock), 0, st, row, col, w, m, n, (const float*)dis, scale, diag, row_out, col_out, val_out);
+  TGCN_CHECK_LAUNCH("adjacency_normalise");
+  *count_host = total;
+  return TGCN_OK;
+}
+
 // --------------------------------------------------------------------------------------------------
 // schedule
 // --------------------------------------------------------------------------------------------------

@@ -128,26 +128,41 @@ int tgcn_graph_create_from_csr(int64_t n, int64_t n_cols, const int64_t* rowptr,
  * vertices without outgoing edges. */
 int tgcn_graph_create_from_edge_index(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_weight, tgcn_graph** out) {
   if (!out || !graph_sizes_ok(n, n, E) || (E > 0 && !edge_index)) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_edge_index: bad argument");
-  hipStream_t st = (hipStream_t)0;
-  DeviceBuf keep, pos, scanws, r, c, v, deg, bad;
+  DeviceBuf ws, r, c, v;
   const size_t m1 = (size_t)(E ? E : 1);
-  if (keep.alloc((m1 + 1) * 8) || pos.alloc((m1 + 1) * 8) || scanws.alloc(scan_ws_elems(E + 1) * 8) || r.alloc(m1 * 8) || c.alloc(m1 * 8) ||
-      v.alloc(m1 * 4) || deg.zero((size_t)n * 4) || bad.zero(sizeof(int)) || hipMemset(keep.p, 0, (m1 + 1) * 8) != hipSuccess)
+  if (ws.alloc(edge_norm_ws_bytes(n, E)) || r.alloc(m1 * 8) || c.alloc(m1 * 8) || v.alloc(m1 * 4))
     TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_edge_index: device allocation failed");
   int64_t kept = 0;
-  if (E > 0) {
-    hipLaunchKernelGGL(edge_keep_kernel, dim3(grid_1d(E)), dim3(kBlock), 0, st, edge_index, E, n, (int64_t*)keep.p, (int*)bad.p);
-    scan_i64(st, (const int64_t*)keep.p, (int64_t*)pos.p, E + 1, 0, (int64_t*)scanws.p);          // pos[E] = number of kept edges
-    int h_bad = 0;
-    if (read_back(&h_bad, (const int*)bad.p) || read_back(&kept, (const int64_t*)pos.p + E)) TGCN_FAIL(TGCN_ERR_LAUNCH, "graph_create_from_edge_index: device read failed");
-    if (h_bad) TGCN_FAIL(TGCN_ERR_INVALID, "graph_create_from_edge_index: vertex index outside [0, %lld)", (long long)n);
-    hipLaunchKernelGGL(edge_compact_kernel, dim3(grid_1d(E)), dim3(kBlock), 0, st, edge_index, edge_weight, E, (const int64_t*)keep.p,
-                       (const int64_t*)pos.p, (int64_t*)r.p, (int64_t*)c.p, (float*)v.p, (unsigned int*)deg.p);
-    if (kept > 0)
-      hipLaunchKernelGGL(edge_normalise_kernel, dim3(grid_1d(kept)), dim3(kBlock), 0, st, (const int64_t*)r.p, (const int64_t*)c.p, (float*)v.p,
-                         (const unsigned int*)deg.p, kept);
-  }
+  const int rc = edge_normalise_device((hipStream_t)0, n, E, edge_index, edge_weight, (int64_t*)r.p, (int64_t*)c.p, (float*)v.p, &kept, (char*)ws.p);
+  if (rc != TGCN_OK) return rc;
   return graph_from_device_coo(n, n, kept, (const int64_t*)r.p, (const int64_t*)c.p, (const float*)v.p, out);
+}
+
+/* The same normalisation on CALLER memory (ABI v5): the host side that owns its arrays (torch tensors: tgcn_amd/graph.py::from_edge_index)
+ * runs the library's kernels instead of its own arithmetic.  row / col / val: E slots each; *kept (host) = entries written, in the
+ * given order.  Synchronises the stream once (range flag + count). */
+size_t tgcn_edge_normalise_workspace_bytes(int64_t n, int64_t E) { return (n > 0 && E >= 0) ? edge_norm_ws_bytes(n, E) : 0; }
+
+int tgcn_edge_normalise_f32(void* stream, int64_t n, int64_t E, const int64_t* edge_index, const float* edge_weight, int64_t* row, int64_t* col,
+                            float* val, int64_t* kept, void* workspace, size_t workspace_bytes) {
+  if (!kept || !graph_sizes_ok(n, n, E) || (E > 0 && (!edge_index || !row || !col || !val))) TGCN_FAIL(TGCN_ERR_INVALID, "edge_normalise: bad argument");
+  if (!workspace || workspace_bytes < edge_norm_ws_bytes(n, E) || ((uintptr_t)workspace & 255))
+    TGCN_FAIL(TGCN_ERR_WORKSPACE, "edge_normalise: workspace %zu < %zu (256-byte aligned)", workspace_bytes, edge_norm_ws_bytes(n, E));
+  return edge_normalise_device((hipStream_t)stream, n, E, edge_index, edge_weight, row, col, val, kept, (char*)workspace);
+}
+
+/* COO of the weight matrix W -> COO of rescale_L(laplacian(W, normalized=True), lmax) (gcn/graph.py:117-136, 232-238) on caller memory:
+ * d = colsum(W) + eps (one wave per column, fixed summation order), L-hat = (2/lmax) (I - D^-1/2 W D^-1/2) - I.  row_out / col_out /
+ * val_out: m + n slots (the n diagonal entries exist only for lmax != 2); *count (host) = entries written. */
+size_t tgcn_adjacency_normalise_workspace_bytes(int64_t n, int64_t m) { return (n > 0 && m >= 0) ? adjacency_norm_ws_bytes(n, m) : 0; }
+
+int tgcn_adjacency_normalise_f32(void* stream, int64_t n, int64_t m, const int64_t* row, const int64_t* col, const float* weight, float lmax,
+                                 int64_t* row_out, int64_t* col_out, float* val_out, int64_t* count, void* workspace, size_t workspace_bytes) {
+  if (!count || !graph_sizes_ok(n, n, m + n) || !(lmax > 0.f) || !row_out || !col_out || !val_out || (m > 0 && (!row || !col || !weight)))
+    TGCN_FAIL(TGCN_ERR_INVALID, "adjacency_normalise: bad argument");
+  if (!workspace || workspace_bytes < adjacency_norm_ws_bytes(n, m) || ((uintptr_t)workspace & 255))
+    TGCN_FAIL(TGCN_ERR_WORKSPACE, "adjacency_normalise: workspace %zu < %zu (256-byte aligned)", workspace_bytes, adjacency_norm_ws_bytes(n, m));
+  return adjacency_normalise_device((hipStream_t)stream, n, m, row, col, weight, lmax, row_out, col_out, val_out, count, (char*)workspace);
 }
 
 const tgcn_csr* tgcn_graph_csr(const tgcn_graph* g) { return g ? &g->csr : nullptr; }

@@ -5,6 +5,7 @@ tgcn/nn/gcn.py:141,223 and :408-413,505-510) and cached by the modules.  The pre
 plumbing on torch tensors (sort / cumsum / searchsorted); every flop of the layer runs in libtgcn_hip.so.
 """
 
+import ctypes as C
 import threading
 
 import torch
@@ -381,6 +382,13 @@ class GraphOperand:
         deg = number of edges per SOURCE vertex (unweighted), lap_e = -deg^-1/2[row] * w_e * deg^-1/2[col],
         deg^-1/2 = 0 for isolated vertices."""
         device = edge_index.device if device is None else torch.device(device)
+        if edge_weight is not None and edge_weight.requires_grad:
+            raise _lib.TgcnError("edge_weight.requires_grad: the operand is built outside autograd (kernels of the library), so the weight would "
+                                 "silently get no gradient -- detach() it, or keep the reference's modules for learnable edge weights "
+                                 "(lap = -deg[row] * edge_weight * deg[col], tgcn/nn/gcn.py:413,510)")
+        if BUILDER == "library" and device.type == "cuda":
+            return GraphOperand._from_edge_index_library(edge_index, edge_weight, int(n), device)
+        # cross-check form (and CPU rehearsals): the same steps with torch index ops
         row, col = edge_index[0].to(device), edge_index[1].to(device)
         _check_range(row, col, n, n)
         keep = row != col
@@ -388,12 +396,35 @@ class GraphOperand:
         if edge_weight is None:
             w = torch.ones(row.numel(), dtype=torch.float32, device=device)
         else:
-            w = edge_weight.reshape(-1).to(device=device, dtype=torch.float32)[keep]
+            w = edge_weight.detach().reshape(-1).to(device=device, dtype=torch.float32)[keep]
         deg = torch.bincount(row, minlength=n).to(torch.float32)
         dis = deg.pow(-0.5)
         dis[torch.isinf(dis)] = 0
         lap = -dis[row] * w * dis[col]
         return GraphOperand.from_coo(n, row, col, lap, device)
+
+    @staticmethod
+    def _from_edge_index_library(edge_index, edge_weight, n, device):
+        """tgcn_edge_normalise_f32 (keep mask, order-preserving compaction, integer source degrees, -d^-1/2 w d^-1/2) on torch-owned arrays,
+        then the library's COO -> CSR: the product path runs no arithmetic of its own on the edge list"""
+        L = _lib.lib()
+        ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
+        if ei.dim() != 2 or ei.shape[0] != 2:
+            raise _lib.TgcnError("edge_index must be (2, E)")
+        E = int(ei.shape[1])
+        w = None if edge_weight is None else edge_weight.detach().reshape(-1).to(device=device, dtype=torch.float32).contiguous()
+        if w is not None and w.numel() != E:
+            raise _lib.TgcnError("edge_weight has %d entries for %d edges" % (w.numel(), E))
+        row = torch.empty(max(E, 1), dtype=torch.int64, device=device)
+        col = torch.empty(max(E, 1), dtype=torch.int64, device=device)
+        val = torch.empty(max(E, 1), dtype=torch.float32, device=device)
+        kept = C.c_int64(0)
+        with torch.cuda.device(device):
+            ws = torch.empty(max(L.tgcn_edge_normalise_workspace_bytes(n, E), 256), dtype=torch.uint8, device=device)
+            _lib.check(L.tgcn_edge_normalise_f32(_lib.stream_ptr(), n, E, _lib.ptr(ei), _lib.ptr(w), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
+                                                 C.byref(kept), _lib.ptr(ws), ws.numel()))
+        k = int(kept.value)
+        return GraphOperand._from_coo_library(n, row[:k].contiguous(), col[:k].contiguous(), val[:k].contiguous(), device, n)
 
     @staticmethod
     def from_adjacency(n, row, col, weight, lmax=2.0, device=None):
@@ -402,9 +433,26 @@ class GraphOperand:
         the weight matrix W, on the device:  d = colsum(W) + eps,  L = I - D^-1/2 W D^-1/2,  L-hat = L * (2/lmax) - I.
         With lmax = 2 the diagonal cancels and L-hat = -D^-1/2 W D^-1/2."""
         device = row.device if device is None else torch.device(device)
-        row = row.to(device=device, dtype=torch.int64)
-        col = col.to(device=device, dtype=torch.int64)
-        w = weight.to(device=device, dtype=torch.float32)
+        row = row.to(device=device, dtype=torch.int64).contiguous()
+        col = col.to(device=device, dtype=torch.int64).contiguous()
+        w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+        if not (row.numel() == col.numel() == w.numel()):
+            raise _lib.TgcnError("adjacency: row / col / weight lengths differ")
+        if BUILDER == "library" and device.type == "cuda":
+            # tgcn_adjacency_normalise_f32: column sums by a stable sort + one wave per column (fixed order, no float atomics), values, diagonal
+            L = _lib.lib()
+            m = int(row.numel())
+            ro = torch.empty(m + n, dtype=torch.int64, device=device)
+            co = torch.empty(m + n, dtype=torch.int64, device=device)
+            vo = torch.empty(m + n, dtype=torch.float32, device=device)
+            count = C.c_int64(0)
+            with torch.cuda.device(device):
+                ws = torch.empty(max(L.tgcn_adjacency_normalise_workspace_bytes(n, m), 256), dtype=torch.uint8, device=device)
+                _lib.check(L.tgcn_adjacency_normalise_f32(_lib.stream_ptr(), n, m, _lib.ptr(row), _lib.ptr(col), _lib.ptr(w), float(lmax), _lib.ptr(ro),
+                                                          _lib.ptr(co), _lib.ptr(vo), C.byref(count), _lib.ptr(ws), ws.numel()))
+            k = int(count.value)
+            return GraphOperand._from_coo_library(n, ro[:k].contiguous(), co[:k].contiguous(), vo[:k].contiguous(), device, n)
+        # cross-check form (and CPU rehearsals): the same steps with torch index ops
         _check_range(row, col, n, n)
         d = torch.zeros(n, dtype=torch.float32, device=device).index_add_(0, col, w)      # W.sum(axis=0)
         d = d + 1.401298464324817e-45                                                      # np.spacing(float32(0))

@@ -5,13 +5,14 @@ Same constructor / forward signatures, parameter names, shapes and initialisatio
 The forward of every class is one call into libtgcn_hip.so (K-1 CSR hops + MFMA projection); nothing here
 falls back to torch ops or the CPU.
 """
+import collections
 import math
 import threading
 
 import torch
 from torch.nn import Parameter
 
-from . import functional as F
+from . import _lib, functional as F
 from .graph import GraphOperand
 
 
@@ -38,8 +39,10 @@ class _OperandCache:
     data_ptr only name a tensor while it exists -- once freed, the allocator may hand the same address (and Python the
     same id) to a new edge_index of the same shape, which must not find the old operand."""
 
+    MAX_ENTRIES = 16      # least recently used beyond this (a per-subject edge_index in a training loop: pygeo_hcp.py:284 swaps the graph per subject)
+
     def __init__(self):
-        self._d = {}
+        self._d = collections.OrderedDict()
         self._lock = threading.Lock()     # nn.DataParallel runs the replicas' forwards in threads that share this object
 
     # copies and pickles of a module start with an empty cache (entries hold device pointers in ctypes structs)
@@ -50,16 +53,18 @@ class _OperandCache:
         return {}
 
     def __setstate__(self, state):
-        self._d = {}
+        self._d = collections.OrderedDict()
         self._lock = threading.Lock()
 
     def get(self, key, build, sources=()):
         with self._lock:
             hit = self._d.get(key)
             if hit is None:
-                if len(self._d) > 16:
-                    self._d.clear()
                 hit = self._d[key] = (build(), tuple(sources))
+                while len(self._d) > self.MAX_ENTRIES:        # evict the least recently used entry only: the others keep their operands
+                    self._d.popitem(last=False)
+            else:
+                self._d.move_to_end(key)
             return hit[0]
 
 
@@ -217,6 +222,10 @@ _spmm_ops = _OperandCache()
 def _coo_operand(index, value, m, device, n_cols=None):
     """m x n_cols operand: the reference's gather / scatter_add form takes any number of source rows (gcn.py:296-308)."""
     n_cols = int(m if n_cols is None else n_cols)
+    if value is not None and value.requires_grad:
+        raise _lib.TgcnError("spmm: value.requires_grad -- the sparse operand is built outside autograd (packed CSR in the library), so the values would "
+                             "silently get no gradient; detach() them, or use the reference's gather / scatter_add form for learnable values "
+                             "(tgcn/nn/gcn.py:296-308)")
     key = (_tensor_key(index), _tensor_key(value), int(m), n_cols, str(device))
     return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value, device, n_cols=n_cols),
                          sources=(index, value))
