@@ -246,6 +246,15 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
                           const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                           int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo);
 
+/* The same contraction through a ROW MAP (ABI v5; the building block of the compacted layers): tile row m is the caller's
+ * vertex rowmap[m] -- its output row, its bias row, and its row in every term t whose bit t is set in `mapped_terms` (typically term 0 = x in
+ * the caller's labels); the other terms (compact hop tensors) are read at row m.  nbatch samples share the tile rows: sample b reads term t
+ * at a[t] + b * a_bs[t] floats and writes out + b * out_bs (a per-vertex bias row then reaches HBM once per pass).  a_bs: HOST array of
+ * nterms strides (nullable for nbatch = 1).  M = number of mapped rows (one sample); n_vertices = rows of the bias / output per sample. */
+int tgcn_cheb_project_mapped_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a, const int64_t* lda,
+                                 const float* W, const float* bias, int32_t bias_kind, int64_t n_vertices, const int32_t* rowmap,
+                                 uint32_t mapped_terms, int32_t nbatch, const int64_t* a_bs, int64_t out_bs, float* out, int64_t ldo);
+
 /* Streaming time windows (replaces materialising the T-H+1 overlapping windows of
  * load/data_hcp.py:116-154 and running TGCNCheb_H on each): series[t] are the hop tensors of ONE recording,
  * (n_vertices, T) contiguous (term t = L^t applied to the raw series); window w of vertex i is series[t][i, w:w+H].

@@ -277,3 +277,116 @@ def test_hop_streaming_form_keeps_the_result(gpu_device):
         cols, vals = e[rp[r]: rp[r + 1], 0], e[rp[r]: rp[r + 1], 1].copy().view(np.float32).astype(np.float64)
         ref = (vals[:, None] * xc[cols]).sum(0)
         assert np.abs(got[r] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 4: compact hop tensors for the Chebyshev recurrence (ChebConv / ChebTimeConv) and for the training forward + backward
+# ---------------------------------------------------------------------------------------------------------------------------------
+_MODULE_FILES = [p for pre in ("GCNCheb_", "TGCNCheb_", "TGCNChebH_", "ChebConv_", "ChebTimeConv_") for p in golden_files(pre)]
+
+
+@pytest.mark.parametrize("path", _MODULE_FILES, ids=golden_ids(_MODULE_FILES))
+def test_compact_training_path_on_every_module_fixture(path, gpu_device, monkeypatch):
+    """Every module fixture of the reference (all five classes; self loops, degree-0 sources, isolated padded vertices, edge weights,
+    K = 1 ... 25) FORCED through the compact path -- forward kept for training, weight gradient from the compact terms, input gradient
+    as the compact layer on L^T -- against the reference's own outputs AND its own autograd gradients."""
+    from tgcn_amd import functional as F, graph
+    from test_hip_parity import _make_layer, GRAD_TOL
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    monkeypatch.setattr(graph, "COMPACT_MIN_EMPTY", 0.0)
+    monkeypatch.setattr(F, "SMALL_PATH", False)
+    monkeypatch.setattr(F, "PROJECT_FIRST", False)
+    monkeypatch.setattr(F, "choose_layout", lambda q, n, C_row: 0)
+    monkeypatch.setattr(F, "_pad_rows", lambda op, x3, w, mode: (x3, w))      # odd row lengths too (scalar-load forms)
+    g = load_golden(path)
+    layer, extra = _make_layer(g)
+    used = {"fwd": 0, "wgrad": 0, "drv": 0}
+    for name, key in (("compact_forward", "fwd"), ("compact_wgrad", "wgrad"), ("cheb_forward_compact", "drv")):
+        real = getattr(F, name)
+        monkeypatch.setattr(F, name, (lambda real, key: lambda *a, **k: (used.__setitem__(key, used[key] + 1), real(*a, **k))[1])(real, key))
+    x = _dev(g["x"]).requires_grad_(True)
+    out = layer(x, *extra)
+    assert rel_err(out.detach().cpu().numpy(), g["out"]) <= TOL
+    out.backward(_dev(g["grad_out"]))
+    assert rel_err(x.grad.cpu().numpy(), g["grad_x"]) <= GRAD_TOL
+    assert rel_err(layer.weight.grad.cpu().numpy(), g["grad_weight"]) <= GRAD_TOL
+    if int(g["has_bias"]):
+        assert rel_err(layer.bias.grad.cpu().numpy(), g["grad_bias"]) <= GRAD_TOL
+    K = layer.weight.shape[0]
+    if 2 <= K <= 32:
+        assert used["fwd"] >= 1 and used["wgrad"] == 1 and used["fwd"] + used["drv"] >= 2, used     # forward, dW, and dx on L^T
+    # inference of the same module (no basis kept) agrees with the training forward
+    with torch.no_grad():
+        assert rel_err(layer(_dev(g["x"]), *extra).cpu().numpy(), out.detach().cpu().numpy()) <= TOL
+
+
+def _directed_with_isolated(n, m, rng):
+    """skewed DIRECTED edge list over a random relabelling: vertices with entries, vertices that are only pointed at, isolated ones"""
+    perm = rng.permutation(n)
+    live = n // 2
+    u = perm[np.minimum((rng.random(m) ** 3 * (live // 2)).astype(np.int64), live // 2 - 1)]              # sources: a quarter of the vertices
+    v = perm[np.minimum((rng.random(m) ** 3 * live).astype(np.int64), live - 1)]                           # targets: half of them
+    keep = u != v
+    return u[keep], v[keep]
+
+
+@pytest.mark.parametrize("symmetric", [True, False], ids=["symmetric", "referenced-only-vertices"])
+@pytest.mark.parametrize("cls,q,f,g_out,K", [("ChebConv", 2, 16, 24, 5), ("ChebConv", 1, 64, 64, 3), ("ChebTimeConv", 2, 2, 8, 4), ("GCNCheb", 2, 32, 16, 5)])
+def test_compact_layers_equal_uncompacted_layers(cls, q, f, g_out, K, symmetric, gpu_device, monkeypatch):
+    """Both recursions on a 70 k-vertex graph with isolated vertices (and, unsymmetric, vertices that entries point at but that have
+    none of their own: for the Chebyshev recurrence those stay in the compact set, T_k of such a vertex is +-x, not 0): the compact
+    forward / backward against the same module with compaction switched off, and the forward against the oracle."""
+    import tgcn_amd
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(K * 7 + f)
+    n = 70_000
+    u, v = _directed_with_isolated(n, 300_000, rng)
+    if symmetric:
+        u, v = np.concatenate([u, v]), np.concatenate([v, u])
+    H = 6
+    torch.manual_seed(3)
+    if cls == "GCNCheb":
+        deg = np.bincount(u, minlength=n).astype(np.float64)
+        dis = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1)), 0.0)
+        val = (-dis[u] * dis[v]).astype(np.float32)
+        op = tgcn_amd.GraphOperand.from_coo(n, _dev(u), _dev(v), _dev(val))
+        layer, extra = tgcn_amd.GCNCheb(op, f, g_out, K).cuda(), ()
+        x = rng.standard_normal((q, n, f)).astype(np.float32)
+        mode, plan = F.MODE_POWER, op.compact_plan("rows")
+    else:
+        ei = _dev(np.stack([u, v]))
+        extra = (ei,)
+        if cls == "ChebConv":
+            layer = tgcn_amd.ChebConv(f, g_out, K).cuda()
+            x = rng.standard_normal((q, n, f)).astype(np.float32)
+        else:
+            layer = tgcn_amd.ChebTimeConv(f, g_out, K, H).cuda()
+            x = rng.standard_normal((q, n, H, f)).astype(np.float32)
+        op = layer._operand(_dev(x), ei, None)
+        mode, plan = F.MODE_CHEBYSHEV, op.compact_plan("closed")
+    assert plan is not None and plan.n_empty >= n // 8
+    if mode == F.MODE_CHEBYSHEV and not symmetric:
+        assert plan.n_c > op.compact_plan("rows").n_c          # referenced-only vertices are kept for the Chebyshev recurrence
+    gout = rng.standard_normal((q, n, g_out)).astype(np.float32)
+    res = {}
+    for compact in (True, False):
+        monkeypatch.setattr(F, "COMPACT", compact)
+        layer.zero_grad()
+        xd = _dev(x).requires_grad_(True)
+        out = layer(xd, *extra)
+        out.backward(_dev(gout))
+        res[compact] = [t.detach().cpu().numpy() for t in (out, xd.grad, layer.weight.grad, layer.bias.grad)]
+    for a, b in zip(res[True], res[False]):
+        assert rel_err(a, b) <= 2e-5
+    # forward against the oracle
+    Ls = op.to_scipy()
+    W = layer.weight.detach().cpu().numpy().reshape(K, -1, g_out)
+    x3 = x.reshape(q, n, -1)
+    if mode == F.MODE_POWER:
+        ref = O.gcn_cheb_forward(Ls, x3, W, layer.bias.detach().cpu().numpy())
+    else:
+        T = [x3, O._apply(Ls, x3)]
+        for k in range(2, K):
+            T.append(2 * O._apply(Ls, T[k - 1]) - T[k - 2])
+        ref = sum(T[k] @ W[k] for k in range(K)) + layer.bias.detach().cpu().numpy()
+    assert rel_err(res[True][0], ref) <= TOL

@@ -115,7 +115,7 @@ def test_library_graph_entry_points_from_csr_and_edge_index(gpu_device):
 def test_edge_list_operand_by_the_library_equals_torch_builder(n, E, weighted, gpu_device, monkeypatch):
     """GraphOperand.from_edge_index on the product path = tgcn_edge_normalise_f32 + tgcn_csr_build_f32 (one builder).
     Against the torch index-op form kept as the cross-check: same entries in the same order (self loops, duplicates, vertices without
-    outgoing edges, weights); the values agree to the last bit (integer degrees, 1/sqrtf and two multiplies on both sides)."""
+    outgoing edges, weights); the values agree to a few ulp (integer degrees on both sides; torch.pow(-0.5) against 1 / sqrtf)."""
     from tgcn_amd import graph
     rng = np.random.default_rng(n + E)
     ei = torch.as_tensor(rng.integers(0, n, (2, E))).cuda()
@@ -130,7 +130,7 @@ def test_edge_list_operand_by_the_library_equals_torch_builder(n, E, weighted, g
     assert a.nnz == b.nnz and torch.equal(a.rowptr, b.rowptr)
     assert torch.equal(a.edges[: a.nnz, 0], b.edges[: b.nnz, 0])
     va, vb = a.edges[: a.nnz, 1].contiguous().view(torch.float32), b.edges[: b.nnz, 1].contiguous().view(torch.float32)
-    assert torch.allclose(va, vb, rtol=2e-7, atol=0)
+    assert torch.allclose(va, vb, rtol=1e-6, atol=0)          # deg.pow(-0.5) against 1 / sqrtf(deg): a few ulp
 
 
 def test_edge_list_operand_rejects_bad_input(gpu_device):

@@ -236,6 +236,15 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
   return project_impl(stream, M, Kc, N, nterms, a, lda, W, bias, bias_kind, n_vertices, interleave, accumulate, out, ldo, 0, 0);
 }
 
+int tgcn_cheb_project_mapped_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a, const int64_t* lda,
+                                 const float* W, const float* bias, int32_t bias_kind, int64_t n_vertices, const int32_t* rowmap,
+                                 uint32_t mapped_terms, int32_t nbatch, const int64_t* a_bs, int64_t out_bs, float* out, int64_t ldo) {
+  if (!rowmap || nbatch < 1 || (nbatch > 1 && !a_bs) || (mapped_terms & kProjMapTermsOnly)) TGCN_FAIL(TGCN_ERR_INVALID, "project_mapped: bad argument");
+  int64_t zero_bs[kMaxTerms] = {0};
+  return project_impl(stream, M, Kc, N, nterms, a, lda, W, bias, bias_kind, n_vertices, 1, 0, out, ldo, 0, 0, -1, rowmap, mapped_terms, nbatch,
+                      a_bs ? a_bs : zero_bs, out_bs);
+}
+
 int tgcn_cheb_project_windows_f32(void* stream, int64_t n_vertices, int32_t T, int32_t H, int32_t N, int32_t nterms,
                                   const float* const* series, const float* W, const float* bias, int32_t bias_kind,
                                   float* out) {

@@ -271,6 +271,141 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
     return out
 
 
+COMPACT_SLAB_BYTES = 64 << 20    # a hop launch covers one sample when a sample's (n_c, C) slab is larger (the gather working set stays one slab)
+
+
+def compact_plan_for(op, mode, K, q, n, C_row):
+    """The graph.CompactPlan a layer of this shape runs on, or None: square operands with enough vertices to leave out of the hop tensors
+    (graph.GraphOperand.compact_plan), 2 <= K <= 32, rows in the (q, n, C) layout.  Mode 0 keeps the rows with entries, mode 1 also every
+    referenced vertex (closed form T_k[i] = x[i], 0, -x[i], ... for the isolated rest)."""
+    if not COMPACT or not (2 <= K <= 32) or op.n != op.n_cols or choose_layout(q, n, C_row) != 0:
+        return None
+    return op.compact_plan("rows" if mode == MODE_POWER else "closed")
+
+
+def _compact_buffer(plan, q, C_row, device):
+    """(q, n_c + 1, C): row n_c of every sample is the zero row entries pointing at a left-out vertex gather from"""
+    t = torch.empty((q, plan.n_c + 1, C_row), dtype=torch.float32, device=device)
+    t[:, plan.n_c].zero_()
+    return t
+
+
+def _gather_rows(src3, rows64, plan):
+    """src3[:, rows] into a compact buffer (index plumbing; one contiguous (n_c, C) block per sample)"""
+    out = _compact_buffer(plan, src3.shape[0], src3.shape[2], src3.device)
+    for b in range(src3.shape[0]):
+        torch.index_select(src3[b], 0, rows64, out=out[b, : plan.n_c])
+    return out
+
+
+def _compact_hop(op, X, Y, plan, z=None, alpha=1.0, beta=0.0):
+    """Y[:, :n_c] = alpha * op X + beta * z[:, :n_c]; one launch per sample when a sample's slab is beyond COMPACT_SLAB_BYTES"""
+    q = X.shape[0]
+    n_c = plan.n_c
+    per_sample = q > 1 and n_c * X.shape[2] * 4 > COMPACT_SLAB_BYTES
+    for sl in ([slice(b, b + 1) for b in range(q)] if per_sample else [slice(0, q)]):
+        csr_hop(op, X[sl], z=None if z is None else z[sl, :n_c], alpha=alpha, beta=beta, out=Y[sl, :n_c])
+
+
+def compact_terms(plan, x3, K, mode):
+    """The K terms of the layer's basis with hop tensors for the plan's n_c kept vertices only.
+    mode 0: [x3, P_1, ..., P_{K-1}], P_k = L^k x (monomials: the basis of the FOLDED weight); term 0 is x itself in the caller's labels.
+    mode 1: [T_0, ..., T_{K-1}] Chebyshev, every term compact (T_0 = x gathered to the kept rows).
+    Compact terms are (q, n_c + 1, C) buffers whose last row is zero."""
+    q, n, Crow = x3.shape
+    dev = x3.device
+    if mode == MODE_POWER:
+        terms = [x3]
+        for k in range(1, K):
+            Y = _compact_buffer(plan, q, Crow, dev)
+            _compact_hop(plan.first if k == 1 else plan.rest, terms[k - 1], Y, plan)
+            terms.append(Y)
+        return terms
+    rows64 = plan.rows.long()
+    terms = [_gather_rows(x3, rows64, plan)]
+    for k in range(1, K):
+        Y = _compact_buffer(plan, q, Crow, dev)
+        if k == 1:
+            _compact_hop(plan.rest, terms[0], Y, plan)
+        else:
+            _compact_hop(plan.rest, terms[k - 1], Y, plan, z=terms[k - 2], alpha=2.0, beta=-1.0)
+        terms.append(Y)
+    return terms
+
+
+def left_out_weight(W_kcn, mode):
+    """(C, N) matrix of the vertices a plan leaves out: out[i] = x[i] @ this + bias.  mode 0 (W in the monomial basis): W'_0 -- every
+    P_k[i], k >= 1, is zero.  mode 1: W_0 - W_2 + W_4 - ... -- T_k[i] = x[i], 0, -x[i], 0, ... for an isolated vertex."""
+    if mode == MODE_POWER:
+        return W_kcn[0].contiguous()
+    K = W_kcn.shape[0]
+    sign = torch.tensor([(1.0 if k % 4 == 0 else -1.0) if k % 2 == 0 else 0.0 for k in range(K)], dtype=W_kcn.dtype, device=W_kcn.device)
+    return (W_kcn * sign.view(K, 1, 1)).sum(0).contiguous()
+
+
+def project_mapped(terms, term_bs, W2d, bias, bias_kind, n_vertices, rowmap, mapped_terms, q, out):
+    """out[b, rowmap[m]] = sum_t terms[t][b, row_t(m)] @ W[t] + bias through tgcn_cheb_project_mapped_f32; terms: tensors whose sample b starts
+    term_bs[t] floats after sample b-1; W2d: (T*Kc, N); out: (q, n_vertices, N) contiguous"""
+    L = _lib.lib()
+    T = len(terms)
+    Kc = W2d.shape[0] // T
+    N = W2d.shape[1]
+    M = int(rowmap.numel())
+    if M == 0:
+        return out
+    a = (C.c_void_p * T)(*[t.data_ptr() for t in terms])
+    lda = (C.c_int64 * T)(*[Kc] * T)
+    a_bs = (C.c_int64 * T)(*term_bs)
+    _lib.check(L.tgcn_cheb_project_mapped_f32(_lib.stream_ptr(), M, Kc, N, T, a, lda, _lib.ptr(W2d), _lib.ptr(bias), bias_kind, n_vertices,
+                                              _lib.ptr(rowmap), mapped_terms, q, a_bs, n_vertices * N, _lib.ptr(out), N))
+    return out
+
+
+def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, terms=None):
+    """Layer forward with compact hop tensors from primitive calls of the library (hops on the plan's operands, two row-mapped projections):
+    the form the training forward / backward and the Chebyshev-recurrence classes use (inference of the dense-L classes takes the one-call
+    driver tgcn_cheb_forward_compact_f32, same kernels).  Wt_kcn: (K, C, N) in the WORKING basis (folded for mode 0).
+    -> (out (q, n, N), terms)"""
+    _lib.require_device(x3, Wt_kcn, bias)
+    q, n, Crow = x3.shape
+    K, _, N = Wt_kcn.shape
+    assert x3.is_contiguous() and n == plan.n and 2 <= K <= 32
+    if x3.data_ptr() % 16:
+        x3 = x3.clone()
+    if terms is None:
+        terms = compact_terms(plan, x3, K, mode)
+    out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
+    b = bias.contiguous() if bias is not None else None
+    cbs = (plan.n_c + 1) * Crow
+    if mode == MODE_POWER:        # term 0 = x through the row map, the others compact
+        project_mapped(terms, [n * Crow] + [cbs] * (K - 1), Wt_kcn.reshape(K * Crow, N).contiguous(), b, bias_kind, n, plan.rows, 1, q, out)
+    else:
+        project_mapped(terms, [cbs] * K, Wt_kcn.reshape(K * Crow, N).contiguous(), b, bias_kind, n, plan.rows, 0, q, out)
+    if plan.n_empty:
+        project_mapped([x3], [n * Crow], left_out_weight(Wt_kcn, mode), b, bias_kind, n, plan.empty, 1, q, out)
+    return out, terms
+
+
+def compact_wgrad(plan, x3, terms, g, mode):
+    """dW (K, C, N) in the working basis from compact terms: the kept rows of g are gathered once (g_c), term k >= 1 contracts with them;
+    the left-out vertices enter through x only -- term 0 for mode 0, and with alternating signs at every even k for mode 1 (T_k[i] = +-x[i])."""
+    q, n, Crow = x3.shape
+    N = g.shape[2]
+    K = len(terms)
+    g_c = _gather_rows(g, plan.rows.long(), plan)                             # (q, n_c + 1, N), zero last row
+    gc2 = g_c.reshape(q * (plan.n_c + 1), N)
+    S_all = cheb_wgrad([x3.reshape(q * n, Crow)], g.reshape(q * n, N))[0]     # x^T g over every vertex
+    flat = lambda t: t.reshape(q * (plan.n_c + 1), Crow)
+    if mode == MODE_POWER:
+        rest = cheb_wgrad([flat(t) for t in terms[1:]], gc2) if K > 1 else None
+        return torch.cat([S_all.unsqueeze(0), rest]) if K > 1 else S_all.unsqueeze(0)
+    dW = cheb_wgrad([flat(t) for t in terms], gc2)
+    S_out = S_all - dW[0]                                                      # x^T g over the isolated vertices only
+    for k in range(0, K, 2):
+        dW[k] += S_out if k % 4 == 0 else -S_out
+    return dW
+
+
 def cheb_forward_pool(op, x3, Wt, bias, bias_kind, mode, K, pool, z, idx, layout=None, q_chunk=None):
     """relu + max-pool fused layer on the hops-then-projection path (tgcn_cheb_forward_pool_f32) into z (q, n/pool, N) and the
     arg-max bytes idx.  x3: (q, n, C) contiguous; Wt: (K*C, N) in the working basis."""
@@ -442,9 +577,11 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     Wt = fold_weight(fold, W) if fold is not None else W
     if use_project_first(x3.shape[0], x3.shape[1], Crow, N):
         return cheb_forward_pf(op, x3, Wt, b, bias_kind, mode)
-    plan = op.compact_plan() if (COMPACT and mode == MODE_POWER and 2 <= K <= 32 and choose_layout(x3.shape[0], x3.shape[1], Crow) == 0) else None
-    if plan is not None:            # many structurally empty rows: compact hop tensors
+    plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow)
+    if plan is not None and mode == MODE_POWER:            # many structurally empty rows: compact hop tensors, one call
         return cheb_forward_compact(plan, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, K)
+    if plan is not None:                                   # the same for the Chebyshev recurrence (closed form for isolated vertices)
+        return compact_forward(plan, x3, Wt, b, bias_kind, mode)[0]
     return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
 
 
@@ -498,7 +635,13 @@ class ChebLayerFn(torch.autograd.Function):
         general = not small_path_tile(op, Crow, mode) and not use_project_first(x3.shape[0], x3.shape[1], Crow, N)
         # grad_mode: whether the CALLER records gradients (inside forward() grad mode is always off, and needs_input_grad only
         # mirrors requires_grad): an inference call under torch.no_grad() keeps nothing for a backward that never comes
-        if general and K > 1 and grad_mode and ctx.needs_input_grad[1] and K * x3.numel() * 4 <= KEEP_BASIS_BYTES:
+        plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow) if general else None
+        if plan is not None and grad_mode and ctx.needs_input_grad[1] and K * x3.shape[0] * (plan.n_c + 1) * Crow * 4 <= KEEP_BASIS_BYTES:
+            # training forward on an operand with left-out vertices: compact hop tensors, kept for the weight gradient
+            Wt = fold_weight(fold, W) if fold is not None else W
+            out, terms = compact_forward(plan, x3, Wt, b, bias_kind, mode)
+            ctx.basis = ("compact", plan, terms)
+        elif general and plan is None and K > 1 and grad_mode and ctx.needs_input_grad[1] and K * x3.numel() * 4 <= KEEP_BASIS_BYTES:
             Wt = fold_weight(fold, W) if fold is not None else W
             out, rows, nq = forward_keeping_basis(op, x3, Wt, b, bias_kind, mode)
             ctx.basis = (rows, nq)
@@ -571,7 +714,18 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
     g = g.contiguous()
     g2d = g.reshape(q * n, N)
     gx = gW = gb = None
-    if needs[1] and basis is not None:                                # hop tensors kept by the forward (forward_keeping_basis)
+    general = not small_path_tile(op, Crow, mode) and not use_project_first(q, n, Crow, N)
+    plan = compact_plan_for(op, mode, K, q, n, Crow) if general else None
+    if needs[1] and (plan is not None or (basis is not None and basis[0] == "compact")):
+        # operand with left-out vertices: the basis exists (kept by the forward, or recomputed here) for the kept vertices only
+        if basis is not None and basis[0] == "compact":
+            plan_b, terms = basis[1], basis[2]
+        else:
+            plan_b, terms = plan, compact_terms(plan, x3.contiguous(), K, mode)
+        gW = compact_wgrad(plan_b, x3.contiguous(), terms, g, mode)
+        if fold is not None:
+            gW = fold_weight(fold, gW, transpose=True)
+    elif needs[1] and basis is not None:                              # hop tensors kept by the forward (forward_keeping_basis)
         rows, nq = basis
         g_rows = relayout_qnc_to_nqc(g).view(q * n, N) if nq else g2d     # same (vertex, sample) row order as the terms
         gW = cheb_wgrad(rows, g_rows)
@@ -589,6 +743,14 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
     if needs[0] and small_path_tile(op.transpose(), N, mode):
         # small graphs: dx = sum_j (L^T)^j g W_j^T is the one-launch forward kernel on (L^T, g, W^T)
         gx = cheb_forward_small(op.transpose(), g, Wt.permute(0, 2, 1).contiguous(), None, None, BIAS_NONE, mode)
+    elif needs[0] and general and compact_plan_for(op.transpose(), mode, K, q, n, N) is not None:
+        # dx = sum_k T_k(L^T) g W_k^T IS the layer on (L^T, g, W^T): with left-out vertices in L^T it runs on compact hop tensors too
+        planT = compact_plan_for(op.transpose(), mode, K, q, n, N)
+        WtT = Wt.permute(0, 2, 1).contiguous()                       # (K, N, C)
+        if mode == MODE_POWER:
+            gx = cheb_forward_compact(planT, g, WtT.reshape(K * N, Crow), None, BIAS_NONE, K)
+        else:
+            gx = compact_forward(planT, g, WtT, None, BIAS_NONE, mode)[0]
     elif needs[0]:
         opT = op.transpose()
         # G[m, k*C + c] = sum_n g[m, n] W[k, c, n]: one projection with the (N, K*C) transposed weight
@@ -639,7 +801,7 @@ class ChebReluPoolFn(torch.autograd.Function):
                                                           _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
                                                           _lib.ptr(z), _lib.ptr(idx)))
         elif (not small_path_tile(op, Crow, mode) and not use_project_first(q, n, Crow, N)
-              and not (COMPACT and mode == MODE_POWER and 2 <= K <= 32 and choose_layout(q, n, Crow) == 0 and op.compact_plan() is not None)):
+              and compact_plan_for(op, mode, K, q, n, Crow) is None):
             # hops-then-projection path: bias + relu + max over `pool` vertices inside the projection's epilogue where the shape allows
             # (tgcn_cheb_forward_pool_f32: the (q, n, N) layer output is then never written), one extra pass over scratch otherwise
             Wt = fold_weight(fold, W) if fold is not None else W

@@ -193,8 +193,9 @@ class CompactPlan:
     empty vertex points at the zero row n_c -- for hops 2..K-1; `rows` / `empty` = caller's label of every compact / empty
     row, ascending.  Both operands share one schedule (same row pointers, same entry order)."""
 
-    def __init__(self, op, keep):
+    def __init__(self, op, keep, kind="rows"):
         dev = op.device
+        self.kind = kind                            # "rows": keep = rows with entries; "closed": also every vertex an entry points at
         self.n = op.n
         rows = keep.nonzero().flatten()
         self.n_c = int(rows.numel())
@@ -263,17 +264,34 @@ class GraphOperand:
         self.perm = None          # reordered(): internal row i holds the caller's vertex perm[i]
         self.inv_perm = None
 
-    def compact_plan(self):
-        """CompactPlan when enough rows are structurally empty for compact hop tensors to pay, else None (built once)."""
+    def compact_plan(self, kind="rows"):
+        """CompactPlan when enough vertices can be left out of the hop tensors for that to pay, else None (built once per kind).
+        kind "rows" (reference_power recursion): the kept vertices are the rows with stored entries -- P_k[i] = 0, k >= 1, for the others, and
+        an entry pointing at one of them reads a zero row.  kind "closed" (true Chebyshev recursion, where T_k of an empty row is +-x, not 0):
+        additionally every vertex some entry points at, so that the left-out vertices are ISOLATED (no entries, never referenced) and
+        T_k[i] = x[i], 0, -x[i], 0, ... holds for them in closed form.  Symmetric patterns give the same set for both: one plan is shared."""
+        assert kind in ("rows", "closed")
         with self._lock:
             if self._compact is False:
-                self._compact = None
+                self._compact = {}
+            if kind not in self._compact:
+                plan = None
                 if self.n == self.n_cols and self.n >= COMPACT_MIN_ROWS and self.nnz > 0:
                     keep = self.rowptr[1:] > self.rowptr[:-1]
-                    n_c = int(keep.sum().item())
-                    if 0 < n_c and (self.n - n_c) >= COMPACT_MIN_EMPTY * self.n:
-                        self._compact = CompactPlan(self, keep)
-            return self._compact
+                    shared = False
+                    if kind == "closed":
+                        ref = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+                        ref[self.edges[: self.nnz, 0].long()] = True
+                        if bool((ref & ~keep).any().item()):
+                            keep = keep | ref
+                        else:                                 # same vertex set: the "rows" plan serves both recursions
+                            plan, shared = self.compact_plan("rows"), True
+                    if not shared:
+                        n_c = int(keep.sum().item())
+                        if 0 < n_c and (self.n - n_c) >= COMPACT_MIN_EMPTY * self.n:
+                            plan = CompactPlan(self, keep, kind)
+                self._compact[kind] = plan
+            return self._compact[kind]
 
     def __deepcopy__(self, memo):
         """An operand is immutable once built (device arrays + ctypes structs that point into them): copies of a module share it."""
