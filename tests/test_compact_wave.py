@@ -390,3 +390,48 @@ def test_compact_layers_equal_uncompacted_layers(cls, q, f, g_out, K, symmetric,
             T.append(2 * O._apply(Ls, T[k - 1]) - T[k - 2])
         ref = sum(T[k] @ W[k] for k in range(K)) + layer.bias.detach().cpu().numpy()
     assert rel_err(res[True][0], ref) <= TOL
+
+
+@pytest.mark.parametrize("symmetric", [True, False], ids=["symmetric", "entries-into-empty-rows"])
+@pytest.mark.parametrize("q,C,N,K,bias_kind,q_chunk", [(3, 64, 64, 5, 2, 1), (4, 64, 64, 3, 2, 2), (2, 64, 32, 2, 1, 1), (1, 32, 16, 4, 0, 1), (2, 128, 64, 3, 2, 2)])
+def test_last_hop_fused_into_the_projection_is_bitwise_the_unfused_forward(q, C, N, K, bias_kind, q_chunk, symmetric, gpu_device, monkeypatch):
+    """the compacted driver gathers the rows of at most 32 entries of the LAST hop inside the projection
+    (project_x3_gather_kernel) and runs the hop launch for the longer rows only; the last hop tensor is not written for the others.
+    Same per-row arithmetic (stored-order fmaf chain, same bf16x3 split and MFMA order) => bitwise the result of hop + projection
+    (tgcn_set_tuning("fuse_last_hop", 0)), and within 1e-5 of the oracle.  K = 2: the fused hop gathers from x through the caller-label operand."""
+    from tgcn_amd import functional as F, graph, _lib
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    n = 40000
+    rng = np.random.default_rng(q * 10 + C + K)
+    row, col, val = _rmat_like(n, 60000, rng, symmetric)
+    op = graph.GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    plan = op.compact_plan()
+    assert plan is not None
+    sched = plan.schedule_for(C, True)
+    assert sched.nseg > 0 and sched.nlong > 0           # rows above the threshold exist: they take the hop launch, the others the gather
+    x = _dev(rng.standard_normal((q, n, C)).astype(np.float32))
+    W = _dev((rng.standard_normal((K, C, N)) / np.sqrt(K * C)).astype(np.float32))
+    bias = None if bias_kind == 0 else _dev(rng.standard_normal((N,) if bias_kind == 1 else (n, N)).astype(np.float32))
+    W2 = W.reshape(K * C, N).contiguous()
+    L = _lib.lib()
+    _lib.check(L.tgcn_set_tuning(b"project_variant", 3))          # the bf16x3 kernel at this size too (auto takes it from 8192 rows)
+    try:
+        outs = []
+        for fuse in (1, 0):
+            _lib.check(L.tgcn_set_tuning(b"fuse_last_hop", fuse))
+            _lib.profile_start(256)
+            outs.append(F.cheb_forward_compact(plan, x, W2, bias, bias_kind, K, q_chunk=q_chunk))
+            prof = _lib.profile_stop(256)
+            hops = sum(1 for kind, _ in prof if kind == 0)
+            assert hops == q * (K - 1), (fuse, hops)
+    finally:
+        L.tgcn_reset_tuning()
+    assert torch.equal(outs[0], outs[1])
+    Ls = op.to_scipy()
+    P = [x.cpu().numpy()]
+    for _ in range(1, K):
+        P.append(O._apply(Ls, P[-1]))
+    ref = sum(P[k].astype(np.float64) @ W[k].cpu().numpy().astype(np.float64) for k in range(K))
+    if bias is not None:
+        ref = ref + bias.cpu().numpy()
+    assert rel_err(outs[0].cpu().numpy(), ref) <= TOL

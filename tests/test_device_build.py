@@ -161,4 +161,16 @@ def test_adjacency_operand_by_the_library_equals_torch_builder(n, m, lmax, gpu_d
     assert torch.equal(a.edges[: a.nnz], a2.edges[: a.nnz])          # deterministic: no float atomics
     assert torch.equal(a.edges[: a.nnz, 0], b.edges[: b.nnz, 0])
     va, vb = a.edges[: a.nnz, 1].contiguous().view(torch.float32), b.edges[: b.nnz, 1].contiguous().view(torch.float32)
-    assert torch.allclose(va, vb, rtol=1e-5, atol=1e-30)             # column sums of thousands of terms in another order
+    assert torch.allclose(va, vb, rtol=1e-3, atol=1e-30)             # the torch form sums a hub column's 10^5 terms with fp32 atomics in any order
+    # the bar: the same values computed in float64 (the reference computes d = W.sum(axis=0) in W's dtype on the host, gcn/graph.py:124)
+    d = torch.zeros(n, dtype=torch.float64, device="cuda").index_add_(0, col, w.double()) + 1.401298464324817e-45
+    dis = 1.0 / torch.sqrt(d)
+    ref = -(2.0 / lmax) * dis[row] * w.double() * dis[col]
+    # entries of the operand are sorted by (row, col) with duplicates in their given order: sort the reference the same way
+    if lmax != 2.0:
+        diag = torch.arange(n, device="cuda")
+        row2, col2, ref = torch.cat([row, diag]), torch.cat([col, diag]), torch.cat([ref, torch.full((n,), 2.0 / lmax - 1.0, dtype=torch.float64, device="cuda")])
+    else:
+        row2, col2 = row, col
+    order = torch.argsort(row2 * n + col2, stable=True)
+    assert torch.allclose(va.double(), ref[order], rtol=1e-5, atol=1e-30)

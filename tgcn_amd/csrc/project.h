@@ -39,6 +39,15 @@ struct ProjParams {
   // no interleave, no accumulate; pool divides 16.
   int32_t pool;
   uint8_t* pool_idx;
+  // Fused LAST HOP (compacted forward, project_x3_gather_kernel): term g_term of tile row m is not read from memory but gathered --
+  // S[m] = sum_e val_e * g_X[col_e] over the stored entries [g_rowptr[m], g_rowptr[m + 1]) of compact row m, summed in stored order with
+  // fmaf exactly like hop_kernel's row blocks -- when the row has at most g_thresh entries; longer rows read a[g_term] as usual (the
+  // segment path of the hop kernel wrote them).  The hop tensor of the last hop is then neither written nor read for ~95 % of the rows.
+  const int32_t* g_rowptr;
+  const tgcn_edge* g_edges;
+  const float* g_X;
+  int64_t g_xbs;
+  int32_t g_term, g_thresh;
 };
 
 // relu + max over p.pool consecutive rows of a wave's finished tile rows held in LDS scratch (`rows` rows of `stride` floats, NW
@@ -279,6 +288,240 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
         const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
         const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
         const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rr) * lda + kc);
+        ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
+      }
+    } else {      // thread = (row, k pair)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int row = (tid >> 4) + h * 32, kk = (tid & 15) * 2;
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = (m0 + row < p.M) && (k0 + kk + j < p.Kc);
+          const float v = A[proj_row_off(p, proj_arow(p, term, rr), lda) + (ok ? k0 + kk + j : 0)];
+          ra[h * 2 + j] = ok ? v : 0.f;
+        }
+      }
+    }
+    {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        const int idx = min(tid + h * XT, KT / 2 * NW - 1);
+        const int cc = idx % NW, kk = (idx / NW) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = (k0 + kk + j < p.Kc) && (n0 + cc < p.N);
+          const float v = Wt[(int64_t)(ok ? k0 + kk + j : 0) * p.N + (ok ? n0 + cc : 0)];
+          rw[h * 2 + j] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+  auto store_tile = [&]() {      // split into the three bf16 planes on the way into LDS
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 64, kk = (tid & 7) * 4;
+        unsigned a1, a2, a3, b1, b2, b3;
+        split3(ra[h * 4 + 0], ra[h * 4 + 1], a1, a2, a3);
+        split3(ra[h * 4 + 2], ra[h * 4 + 3], b1, b2, b3);
+        const int o = row * RS + x3_chunk(row, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<uint2*>(&Ap[0][o]) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(&Ap[1][o]) = make_uint2(a2, b2);
+        *reinterpret_cast<uint2*>(&Ap[2][o]) = make_uint2(a3, b3);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int row = (tid >> 4) + h * 32, kk = (tid & 15) * 2;
+        unsigned a1, a2, a3;
+        split3(ra[h * 2 + 0], ra[h * 2 + 1], a1, a2, a3);
+        const int o = row * RS + x3_chunk(row, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<unsigned*>(&Ap[0][o]) = a1;
+        *reinterpret_cast<unsigned*>(&Ap[1][o]) = a2;
+        *reinterpret_cast<unsigned*>(&Ap[2][o]) = a3;
+      }
+    }
+    {
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {       // W tile transposed: [column][k], so a fragment's 8 k are contiguous
+        const int idx = tid + h * XT;
+        if (idx >= KT / 2 * NW) continue;
+        const int cc = idx % NW, kk = (idx / NW) * 2;
+        unsigned w1, w2, w3;
+        split3(rw[h * 2 + 0], rw[h * 2 + 1], w1, w2, w3);
+        const int o = cc * RS + x3_chunk(cc, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<unsigned*>(&Wp[0][o]) = w1;
+        *reinterpret_cast<unsigned*>(&Wp[1][o]) = w2;
+        *reinterpret_cast<unsigned*>(&Wp[2][o]) = w3;
+      }
+    }
+  };
+
+  load_tile(0);
+  const int frag = (lane & 15) * RS + x3_chunk(lane & 15, lane >> 4) * 8;   // this lane's 8 consecutive k of row / column (lane & 15)
+  for (int ti = 0; ti < total; ++ti) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (ti + 1 < total) load_tile(ti + 1);
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[r][pl] = *reinterpret_cast<const bf16x8*>(&Ap[pl][(wave * 32 + r * 16) * RS + frag]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 w[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8*>(&Wp[pl][(nt * 16) * RS + frag]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {      // smallest terms first
+        f32x4 c = acc[r][nt];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][2], w[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][1], w[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][0], w[0], c, 0, 0, 0);
+        acc[r][nt] = c;
+      }
+    }
+  }
+  // ---- epilogue
+  if constexpr (NT <= 4) {
+    if (p.vec_epilogue) {
+      // accumulators -> wave-private scratch (the A planes are free now) -> float4 rows: coalesced bias loads, 16-byte stores
+      constexpr int ES = NW + 4;                       // scratch row stride in floats
+      constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
+      __syncthreads();                                 // every wave is done reading the last tile's planes
+      float* my = reinterpret_cast<float*>(&Ap[0][0]) + wave * (16 * ES);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * ES + nt * 16 + (lane & 15)] = acc[r][nt][i];
+        if (p.pool > 1) {            // relu + max over consecutive vertices instead of the plain store (wave-uniform branch)
+          pooled_store(p, my, ES, 16, m0 + wave * 32 + r * 16, n0, NW, lane);
+          continue;
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+          const int64_t m = m0 + wave * 32 + r * 16 + row;
+          const int col = n0 + seg;
+          if (m >= p.M || col >= p.N) continue;
+          float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
+          const int64_t orow = proj_orow(p, m);
+          if (p.bias_kind && col < p.bias_cols) {
+            const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          float4* o = reinterpret_cast<float4*>(outb + orow * p.ldo + col);
+          if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+          *o = v;
+        }
+      }
+      return;
+    }
+  }
+  const int col_l = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wave * 32 + r * 16 + (lane >> 4) * 4 + i;
+      if (m >= p.M) continue;
+      const int64_t orow = proj_orow(p, m);
+      const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + col_l;
+        if (col >= p.N) continue;
+        float v = acc[r][nt][i];
+        if (p.bias_kind == 1 && col < p.bias_cols) v += p.bias[col];
+        else if (p.bias_kind == 2 && col < p.bias_cols) v += p.bias[vert * p.bias_ld + col];
+        float* o = outb + orow * p.ldo + col;
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
+// ---- project_x3_kernel<NT, true> with the LAST HOP fused in (ProjParams.g_*): the A tiles of term g_term are produced by gathers for
+// the rows of at most g_thresh stored entries.  A thread owns 4 floats of 4 tile rows (as in the plain kernel's tile load); per row it
+// walks the stored entries four at a time -- the 8 threads of a row read the same entries (one request) and each gathers its own 16 bytes
+// of the neighbour row's 128-byte half -- and adds val * x in stored order (fmaf), so the values equal hop_kernel's bit for bit.
+// Everything else (split into bf16 planes, MFMA order, epilogue) is the plain kernel's, hence the same results as hop + projection.
+template <int NT>
+__global__ __launch_bounds__(512) void project_x3_gather_kernel(const ProjParams p) {
+  constexpr bool VEC4 = true;
+  constexpr int XT = 512;                          // 8 waves x 32 rows: one W tile (and its split) serves 256 rows
+  constexpr int BM = 256, KT = 32, RS = KT;       // LDS rows of 32 bf16 (64 B), 16-byte chunks XOR-swizzled (x3_chunk)
+  constexpr int NW = NT * 16;
+  constexpr int WPAIRS = (KT / 2 * NW + XT - 1) / XT;  // (k, k+1) pairs of one column per thread
+  __shared__ __align__(16) unsigned short Ap[3][BM * RS];
+  __shared__ __align__(16) unsigned short Wp[3][NW * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bb = (int)(blockIdx.x % (unsigned)p.nbatch);          // sample of the batch: consecutive workgroups share a tile
+  const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)p.nbatch) * BM;
+  const int n0 = blockIdx.y * NW;
+  float* const outb = p.out + (int64_t)bb * p.out_bs;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = (p.Kc + KT - 1) / KT;
+  const int total = p.nterms * ktiles;
+
+  float ra[16], rw[2 * WPAIRS];
+  auto load_tile = [&](int ti) {
+    const int term = ti / ktiles, k0 = (ti % ktiles) * KT;
+    const float* __restrict__ A = p.a[term] + (int64_t)bb * p.a_bs[term];
+    const int64_t lda = p.lda[term];
+    const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int row = (tid >> 3) + h * 64, kk = (tid & 7) * 4;
+        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
+        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+        if (term == p.g_term) {
+          // tile row rr of the gathered term is compact row rr (hop tensors are never row-mapped)
+          const int e0 = p.g_rowptr[rr], e1 = p.g_rowptr[rr + 1];
+          if (e1 - e0 <= p.g_thresh) {
+            const float* __restrict__ Xg = p.g_X + (int64_t)bb * p.g_xbs + kc;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int e = e0; e < e1; e += 4) {
+              int c[4];
+              float w[4];
+              float4 xv[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                c[u] = 0; w[u] = 0.f;
+                if (e + u < e1) { const tgcn_edge t = p.g_edges[e + u]; c[u] = t.col; w[u] = t.val; }
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e + u < e1) xv[u] = *reinterpret_cast<const float4*>(Xg + (int64_t)c[u] * lda);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (e + u < e1) {      // predicated, not multiplied by zero: Inf / NaN rows of X propagate as in hop_kernel
+                  s0 = fmaf(w[u], xv[u].x, s0); s1 = fmaf(w[u], xv[u].y, s1); s2 = fmaf(w[u], xv[u].z, s2); s3 = fmaf(w[u], xv[u].w, s3);
+                }
+            }
+            ra[h * 4 + 0] = ok ? s0 : 0.f; ra[h * 4 + 1] = ok ? s1 : 0.f; ra[h * 4 + 2] = ok ? s2 : 0.f; ra[h * 4 + 3] = ok ? s3 : 0.f;
+            continue;
+          }
+        }
         const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rr) * lda + kc);
         ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
       }

@@ -53,7 +53,7 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
 void tgcn_reset_tuning(void) {
   g_hop_variant.store(0); g_hop_remap.store(1); g_hop_seg_remap.store(0); g_hop_mix.store(0); g_hop_stream.store(1); g_hop_lds_pad.store(0);
-  g_proj_variant.store(0); g_small_dense.store(2); g_small_narrow.store(1); g_x3_form.store(2); g_compact_proj.store(0); g_x3_tail.store(1);
+  g_proj_variant.store(0); g_small_dense.store(2); g_small_narrow.store(1); g_x3_form.store(2); g_compact_proj.store(0); g_x3_tail.store(1); g_fuse_last.store(1);
   g_overlap.store(0);
 }
 
@@ -70,6 +70,7 @@ int tgcn_set_tuning(const char* key, int32_t value) {
   if (key && strcmp(key, "x3_form") == 0) { g_x3_form.store(value); return TGCN_OK; }
   if (key && strcmp(key, "compact_proj") == 0) { g_compact_proj.store(value); return TGCN_OK; }
   if (key && strcmp(key, "x3_tail") == 0) { g_x3_tail.store(value != 0); return TGCN_OK; }
+  if (key && strcmp(key, "fuse_last_hop") == 0) { g_fuse_last.store(value != 0); return TGCN_OK; }
   if (key && strcmp(key, "overlap") == 0) { g_overlap.store(value); return TGCN_OK; }
   TGCN_FAIL(TGCN_ERR_INVALID, "set_tuning: unknown key");
 }
@@ -115,9 +116,21 @@ int tgcn_csr_hop_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, i
   return tgcn_csr_hop2_f32(stream, A, S, nb, C, X, Z, alpha, beta, nullptr, 0.f, Y, P, workspace, workspace_bytes);
 }
 
+static int hop_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
+                    const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Z2, float gamma,
+                    const tgcn_dense* Y, const tgcn_dense* P, void* workspace, size_t workspace_bytes, int long_rows_only);
+
 int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
                       const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Z2, float gamma,
                       const tgcn_dense* Y, const tgcn_dense* P, void* workspace, size_t workspace_bytes) {
+  return hop_impl(stream, A, S, nb, C, X, Z, alpha, beta, Z2, gamma, Y, P, workspace, workspace_bytes, 0);
+}
+
+// long_rows_only: the rows of more than row_thresh entries only (whole-row wave segments, lane-group segments + fix-up) -- the others are
+// left to the caller (the projection with the fused last hop gathers them itself); the rows it skips are not written.
+static int hop_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, int32_t nb, int32_t C,
+                    const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Z2, float gamma,
+                    const tgcn_dense* Y, const tgcn_dense* P, void* workspace, size_t workspace_bytes, int long_rows_only) {
   if (!A || !S || !X || !X->ptr) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null operand");
   if ((!Y || !Y->ptr) && (!P || !P->ptr)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: no output");
   if (A->n <= 0 || A->nnz < 0 || A->nnz >= (int64_t)INT32_MAX || A->n >= (int64_t)INT32_MAX)
@@ -162,6 +175,11 @@ int tgcn_csr_hop2_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, 
     p.mix_period = (mix == 1 || (mix == 0 && S->row_mix)) ? 1 : (mix == 2 ? -1 : 0);
   }
   p.stream_out = ((int64_t)A->n * C * (int64_t)sizeof(float) * nb > ((int64_t)256 << 20)) && g_hop_stream.load();
+  if (long_rows_only) {
+    if (S->nseg == 0) return TGCN_OK;       // no row above the threshold: nothing to do
+    p.nblk = 0;                             // no row blocks: every workgroup of the launch is a segment block
+    p.mix_period = 0;
+  }
   const int gpb = kBlock / g.lpr;
   const int seg_blocks = (S->nseg + gpb - 1) / gpb;
   const dim3 grid((unsigned)(S->nblk + seg_blocks), (unsigned)(nb * g.nchunks));
@@ -175,7 +193,16 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
                         int32_t win_n, int32_t win_t, int32_t bias_cols = -1, const int32_t* rowmap = nullptr, uint32_t mapped = 0,
-                        int32_t nbatch = 1, const int64_t* a_bs = nullptr, int64_t out_bs = 0, int32_t pool = 0, uint8_t* pool_idx = nullptr);
+                        int32_t nbatch = 1, const int64_t* a_bs = nullptr, int64_t out_bs = 0, int32_t pool = 0, uint8_t* pool_idx = nullptr,
+                        const struct ProjGather* gather = nullptr);
+
+// The last hop fused into the projection (ProjParams.g_*): operand, gather source and the term it produces.
+struct ProjGather {
+  const tgcn_csr* A;      // rows = the projection's tile rows (compact rows), columns index rows of X
+  const float* X;         // the previous hop tensor (row stride = the row length Kc), sample stride xbs floats
+  int64_t xbs;
+  int32_t term, thresh;   // term whose tiles are gathered for rows of at most `thresh` entries
+};
 
 // THE dispatch of the projection: which kernel a shape takes.  project_impl launches what this returns and project_pool_fusable asks the
 // same function, so the fused relu + pool epilogue can never be requested from a kernel that does not have it.
@@ -224,6 +251,13 @@ static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterm
   return c;
 }
 
+// Whether the projection of this shape (aligned operands) takes the kernel that has the gathering form (fused last hop).
+static bool project_gather_fusable(int64_t M, int32_t Kc, int32_t N, int32_t nterms, bool has_rowmap) {
+  if (Kc % 4 != 0 || nterms > kMaxTerms) return false;
+  const ProjChoice c = project_choose(M, Kc, N, nterms, true, N % 4 == 0, has_rowmap, false);
+  return c.kernel == kProjX3 && c.nts <= 4;
+}
+
 // Whether the projection of this shape (aligned operands, no row map) ends in a kernel with the fused relu + pool epilogue.
 static bool project_pool_fusable(int64_t M, int32_t Kc, int32_t N, int32_t nterms, int32_t pool) {
   if (pool < 2 || 16 % pool != 0 || M % pool != 0 || N % 4 != 0 || nterms > kMaxTerms) return false;
@@ -259,7 +293,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
                         const int64_t* lda, const float* W, const float* bias, int32_t bias_kind,
                         int64_t n_vertices, int64_t interleave, int32_t accumulate, float* out, int64_t ldo,
                         int32_t win_n, int32_t win_t, int32_t bias_cols, const int32_t* rowmap, uint32_t mapped,
-                        int32_t nbatch, const int64_t* a_bs, int64_t out_bs, int32_t pool, uint8_t* pool_idx) {
+                        int32_t nbatch, const int64_t* a_bs, int64_t out_bs, int32_t pool, uint8_t* pool_idx, const ProjGather* gather) {
   if (nbatch < 1 || (nbatch > 1 && !a_bs)) TGCN_FAIL(TGCN_ERR_INVALID, "project: nbatch %d", nbatch);
   if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "project: bad argument");
   if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
@@ -289,6 +323,16 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     if (rowmap || interleave != 1 || accumulate || win_n != 0 || nbatch != 1 || pool < 2 || 16 % pool != 0 || M % pool != 0 || !choice.pool_epilogue)
       TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: no fused pool epilogue for this shape (M=%lld Kc=%d N=%d terms=%d pool=%d)", (long long)M, Kc, N, nterms, pool);
     p.pool = pool; p.pool_idx = pool_idx;
+  }
+  if (gather) {       // fused last hop: only the bf16x3 kernel with at most 4 column tiles has the gathering form
+    if (choice.kernel != kProjX3 || !vec4 || choice.nts > 4 || pool > 1 || accumulate || interleave != 1 || win_n != 0 || !gather->A || !gather->X ||
+        gather->term < 0 || gather->term >= nterms || gather->A->n != M || ((uintptr_t)gather->X & 15) || (gather->xbs % 4) != 0 ||
+        (rowmap && ((mapped >> gather->term) & 1u)))
+      TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: no gathering form for this shape (M=%lld Kc=%d N=%d terms=%d)", (long long)M, Kc, N, nterms);
+    p.g_rowptr = gather->A->rowptr; p.g_edges = gather->A->edges; p.g_X = gather->X; p.g_xbs = gather->xbs;
+    p.g_term = gather->term; p.g_thresh = gather->thresh;
+  } else {
+    p.g_term = -1;
   }
   p.nbatch = 1;
   if (nbatch > 1) {
@@ -377,6 +421,15 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
       tail_blocks = (M - main_blocks * 256 + 127) / 128;
     }
     const dim3 grid3v2((unsigned)(main_blocks + tail_blocks), grid.y);
+    if (gather) {
+      switch (nts) {
+        case 1: hipLaunchKernelGGL((project_x3_gather_kernel<1>), grid3, dim3(512), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((project_x3_gather_kernel<2>), grid3, dim3(512), 0, st, p); break;
+        default: hipLaunchKernelGGL((project_x3_gather_kernel<4>), grid3, dim3(512), 0, st, p); break;
+      }
+      TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (bf16x3 + fused last hop)");
+      return TGCN_OK;
+    }
 #define TGCN_PROJ3(NTV)                                                                              \
   if (NTV >= 6 && choice.kernel == kProjX3Wide) hipLaunchKernelGGL((project_x3v2_kernel<NTV>), grid3v2, dim3(512), 0, st, p, (int)main_blocks); /* wide outputs: compute-bound */ \
   else if (vec4) hipLaunchKernelGGL((project_x3_kernel<NTV, true>), grid3, dim3(512), 0, st, p);      \
@@ -849,15 +902,23 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
   int64_t a_bs[kMaxTerms];
   a_bs[0] = n * (int64_t)C;
   for (int k = 1; k < K; ++k) a_bs[k] = bs_c;
+  // last hop fused into the projection of the compact rows: where that projection is the bf16x3 kernel with <= 64 output columns
+  // (tgcn_set_tuning("fuse_last_hop", 0) keeps hop + projection; with compact_proj = 1 the projection runs over all vertices instead)
+  const bool fuse_last = g_fuse_last.load() && !(compact_id && g_compact_proj.load() == 1) && ((uintptr_t)x & 15) == 0 &&
+                         project_gather_fusable(n_c, C, N, K, true) && (N % 4 == 0) && (((uintptr_t)out & 15) == 0) &&
+                         (!bias || ((uintptr_t)bias & 15) == 0);
   for (int64_t q0 = 0; q0 < q; q0 += qc) {
     const int64_t qn = (q - q0 < qc) ? (q - q0) : qc;
     const float* x0 = x + q0 * n * C;
-    // hops: one launch per hop and time step (a launch's gather working set stays one (n_c, C) slab)
+    // hops: one launch per hop and time step (a launch's gather working set stays one (n_c, C) slab).
+    // fuse_last: the rows of at most row_thresh entries of the LAST hop are gathered inside the projection (project_x3_gather_kernel); the
+    // hop launch then covers the longer rows only, and the last hop tensor is neither written nor read for the others.
     for (int64_t b = 0; b < qn; ++b)
       for (int k = 1; k < K; ++k) {
         tgcn_dense X = {k == 1 ? const_cast<float*>(x0) + b * n * C : hop_ptr(k - 1) + b * bs_c, 0, C};
         tgcn_dense Y = {hop_ptr(k) + b * bs_c, 0, C};
-        rc = tgcn_csr_hop_f32(stream, k == 1 ? A_first : A_rest, S, 1, C, &X, nullptr, 1.f, 0.f, &Y, nullptr, part, part_bytes);
+        rc = hop_impl(stream, k == 1 ? A_first : A_rest, S, 1, C, &X, nullptr, 1.f, 0.f, nullptr, 0.f, &Y, nullptr, part, part_bytes,
+                      (fuse_last && k == K - 1) ? 1 : 0);
         if (rc != TGCN_OK) return rc;
       }
     // projection of the pass's qn time steps in one launch per row class: the per-vertex bias is read once per pass
@@ -874,7 +935,13 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
       continue;
     }
     // vertices with stored entries: all K terms (x through the row map, hop tensors in compact rows)
-    rc = project_impl(stream, n_c, C, N, K, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, rows, 1u, (int32_t)qn, a_bs, n * (int64_t)N);
+    ProjGather gat;
+    gat.A = (K == 2) ? A_first : A_rest;                                // the last hop's operand and its gather source (hop K-2, or x for K = 2)
+    gat.X = (K == 2) ? x0 : hop_ptr(K - 2);
+    gat.xbs = (K == 2) ? n * (int64_t)C : bs_c;
+    gat.term = K - 1; gat.thresh = S->row_thresh;
+    rc = project_impl(stream, n_c, C, N, K, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, rows, 1u, (int32_t)qn, a_bs, n * (int64_t)N,
+                      0, nullptr, fuse_last ? &gat : nullptr);
     if (rc != TGCN_OK) return rc;
     // the others: P_k = 0 for k >= 1, so out = x W_0 + bias
     if (n_empty > 0) {
