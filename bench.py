@@ -485,8 +485,9 @@ def main():
         value = world * units_per_step * args.steps / dt / 1e9
 
     # ---- roofline of the dominant kernel (hop_kernel): algorithmic bytes per launch / mean launch duration
-    hop_ms = [ms for kind, ms in prof if kind == 0]
-    proj_ms = [ms for kind, ms in prof if kind == 2]
+    hop_ms = [ms for kind, ms in prof if kind == 0]            # full hop launches (every row of the operand)
+    hop_long_ms = [ms for kind, ms in prof if kind == 7]       # last hop fused into the projection: the launch covers the rows above the threshold only
+    proj_ms = [ms for kind, ms in prof if kind in (2, 8)]      # 8: the projection that gathers the last hop's short rows itself
     fix_ms = [ms for kind, ms in prof if kind == 1]
     C_row = H * spec["f"]
     F = q * C_row
@@ -495,7 +496,7 @@ def main():
         F = q * spec["g"]      # project-first: the hops run on the (q, n, C_out) results, not on the C_in*H-wide inputs
     nnz_l, n_l = (sh.op.nnz, sh.owned) if vertex_mode else (op.nnz, op.n)      # what ONE rank's launches process
     bytes_recursion = (K - 1) * (8 * nnz_l + 4 * (n_l + 1) + 8 * n_l * F)
-    n_hop_launches = len(hop_ms) // args.steps if hop_ms else 0
+    n_hop_launches = (len(hop_ms) + len(hop_long_ms)) // args.steps if hop_ms else 0      # hops of one forward, fused or not
     roofline = None
     small_ms = [ms for kind, ms in prof if kind == 4]
     if small_ms and not hop_ms:
@@ -534,8 +535,25 @@ def main():
                         algorithmic_bytes_per_launch=int(bytes_per_launch), launches_per_step=n_hop_launches,
                         path="project-first (hops on C_out-wide rows)" if pf_path else "hops-first",
                         mean_launch_ms=round(mean_ms, 4), hop_ms_per_step=round(float(np.sum(hop_ms)) / args.steps, 3),
+                        full_hop_launches_per_step=len(hop_ms) // args.steps,
+                        hop_long_rows_only_ms_per_step=round(float(np.sum(hop_long_ms)) / args.steps, 3),
                         fixup_ms_per_step=round(float(np.sum(fix_ms)) / args.steps, 3),
                         project_ms_per_step=round(float(np.sum(proj_ms)) / args.steps, 3))
+        # what one hop launch PHYSICALLY has to move once: every stored entry, the row pointers, and each row that is
+        # touched once in and once out -- on the compacted operand only the vertices with entries exist as rows, so this is less than the
+        # SURVEY 8(d) figure above (which prices all n rows): a compaction gain is fewer rows processed, not more bandwidth
+        plan_r = None if (vertex_mode or pf_path or small_ms) else (op.compact_plan() if (_F.COMPACT and 2 <= K <= 32 and _F.choose_layout(q, op.n, C_row) == 0) else None)
+        n_rows = plan_r.n_c if plan_r is not None else n_l
+        launches_per_hop = max(1, n_hop_launches // max(1, K - 1))            # cfg5: one launch per hop and time step
+        phys = 8 * nnz_l + 4 * (n_rows + 1) + 8 * n_rows * (F / launches_per_hop)
+        roofline["physical_bytes_per_launch"] = int(phys)
+        roofline["physical_achieved"] = round(phys / (mean_ms * 1e-3) / 1e9, 1)
+        roofline["physical_frac"] = round(phys / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        roofline["physical_note"] = ("entries + row pointers + each of the %d rows that exist in the hop tensors once in and once out; the entry stream is "
+                                     "read by every launch" % n_rows)
+        if hop_long_ms:
+            roofline["note"] = ("last hop fused into the projection: %d of the %d hop launches per step cover the rows above the threshold only and are NOT in "
+                                "mean_launch_ms; frac is for the full hop launches" % (len(hop_long_ms) // args.steps, n_hop_launches))
         step_s = dt / args.steps
         roofline["whole_step"] = dict(bytes=int(bytes_recursion), achieved=round(bytes_recursion / step_s / 1e9, 1), unit="GB/s",
                                       frac=round(bytes_recursion / step_s / 1e9 / HBM_PEAK_GBPS, 4),

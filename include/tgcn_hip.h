@@ -178,6 +178,8 @@ void tgcn_sched_destroy(tgcn_sched* s);
 #define TGCN_PROF_SMALL 4
 #define TGCN_PROF_WGRAD 5
 #define TGCN_PROF_SMALL_BASIS 6
+#define TGCN_PROF_HOP_LONG 7     /* hop_kernel over the rows above the threshold only (last hop fused into the projection) */
+#define TGCN_PROF_PROJECT_GATHER 8 /* projection with the last hop's short rows gathered inside (project_x3_gather_kernel) */
 int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 

@@ -422,8 +422,10 @@ def test_last_hop_fused_into_the_projection_is_bitwise_the_unfused_forward(q, C,
             _lib.profile_start(256)
             outs.append(F.cheb_forward_compact(plan, x, W2, bias, bias_kind, K, q_chunk=q_chunk))
             prof = _lib.profile_stop(256)
-            hops = sum(1 for kind, _ in prof if kind == 0)
-            assert hops == q * (K - 1), (fuse, hops)
+            full, long_only, gathered = (sum(1 for kind, _ in prof if kind == k) for k in (0, 7, 8))
+            # fused: one hop launch per time step covers the rows above the threshold only, and a projection per pass gathers the rest
+            assert (full, long_only) == ((q * (K - 2), q) if fuse else (q * (K - 1), 0)), (fuse, full, long_only)
+            assert gathered == ((q + q_chunk - 1) // q_chunk if fuse else 0)
     finally:
         L.tgcn_reset_tuning()
     assert torch.equal(outs[0], outs[1])

@@ -444,7 +444,7 @@ template <int VEC>
 int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
 #define TGCN_HOP_CASE(L)                                                                    \
   case L: {                                                                                 \
-    { ProfScope ps(TGCN_PROF_HOP, st);                                                      \
+    { ProfScope ps(p.nblk == 0 ? TGCN_PROF_HOP_LONG : TGCN_PROF_HOP, st);                   \
       if (!(VEC == 4 && g_hop_variant.load() != 0 && launch_hop_variant(L, st, p, grid))) { \
         /* interleave rows only when the grid still fills the chip afterwards */            \
         if (HopRows<L>::value > 1 && (int64_t)p.nblk * grid.y >= 4096)                       \

@@ -404,7 +404,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   if (mb > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: M too large");
   const int tiles = (N + 15) / 16, nts = choice.nts;
   const dim3 grid((unsigned)mb, (unsigned)((tiles + nts - 1) / nts));
-  ProfScope ps(TGCN_PROF_PROJECT, st);
+  ProfScope ps(gather ? TGCN_PROF_PROJECT_GATHER : TGCN_PROF_PROJECT, st);
 #define TGCN_PROJ(NTV)                                                                               \
   if (vec4) hipLaunchKernelGGL((project_kernel<NTV, true>), grid, dim3(kBlock), 0, st, p);             \
   else hipLaunchKernelGGL((project_kernel<NTV, false>), grid, dim3(kBlock), 0, st, p);
