@@ -197,6 +197,9 @@ int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* coun
  *                     4 exact-fp32 auto; 5 vector-ALU narrow kernel wherever it applies
  *   "x3_form"         2 (default) bf16x3 with A fragments from registers for >= 96 output columns; 1 both operands via LDS
  *   "x3_tail"         1 (default): the rows of a thinly filled last round of the wide bf16x3 kernel go out as 128-row tiles; 0: never
+ *   "fuse_last_hop"   1: compacted forward with the last hop's rows of <= 32 entries gathered inside the projection kernel (the last hop tensor is
+ *                     neither written nor read for them; the hop launch covers the longer rows only); bitwise the same result, measured slower
+ *                     on cfg5 (290 -> 329 ms per forward), so default 0: hop + projection
  *   "overlap"         1: projection of pass i on a side stream under the hops of pass i+1 (default 0)
  *   "small_dense"     dense small operands: 2 (default) bf16x3 on the matrix pipe when the batch fills the chip, 1 exact
  *                     fp32 MFMA only, 0 vector-ALU one-launch kernels

@@ -77,7 +77,8 @@ std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
 std::atomic<int> g_overlap{0};
 std::atomic<int> g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS
 std::atomic<int> g_compact_proj{0};     // compacted forward: 0 two row-mapped projections (compact rows, empty rows), 1 one projection over all vertices in order
-std::atomic<int> g_fuse_last{1};        // compacted forward: last hop's short rows gathered inside the projection (project_x3_gather_kernel); 0: hop + projection
+std::atomic<int> g_fuse_last{0};        // compacted forward: 1 = last hop's short rows gathered inside the projection (project_x3_gather_kernel), bitwise the same
+                                         // result; measured SLOWER (cfg5 290 -> 329 ms: the gathers want the hop kernel's occupancy), so 0 = hop + projection ships
 std::atomic<int> g_x3_tail{1};          // project_x3v2_kernel: rows of a thinly filled last round as 128-row tiles (0: 256-row tiles throughout)
 std::atomic<int> g_small_narrow{1};    // C <= 4 inputs of the one-launch path: input-side recursion (0: output-side kernel)
 std::atomic<int> g_small_dense{2};     // small dense operands: 2 bf16x3 matrix pipe, 1 fp32 matrix pipe, 0 vector-ALU kernels only        // layer driver: projection of pass i on a side stream under the hops of pass i+1

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void project_x3_kernel(const ProjParams p) {
 // of the neighbour row's 128-byte half -- and adds val * x in stored order (fmaf), so the values equal hop_kernel's bit for bit.
 // Everything else (split into bf16 planes, MFMA order, epilogue) is the plain kernel's, hence the same results as hop + projection.
 template <int NT>
-__global__ __launch_bounds__(512) void project_x3_gather_kernel(const ProjParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void project_x3_gather_kernel(const ProjParams p) {   // two workgroups per CU like the plain kernel: at most 128 VGPRs
   constexpr bool VEC4 = true;
   constexpr int XT = 512;                          // 8 waves x 32 rows: one W tile (and its split) serves 256 rows
   constexpr int BM = 256, KT = 32, RS = KT;       // LDS rows of 32 bf16 (64 B), 16-byte chunks XOR-swizzled (x3_chunk)
@@ -486,44 +486,71 @@ __global__ __launch_bounds__(512) void project_x3_gather_kernel(const ProjParams
     const int64_t lda = p.lda[term];
     const float* __restrict__ Wt = p.W + (int64_t)term * p.Kc * p.N;
     if constexpr (VEC4) {
+      const int kk = (tid & 7) * 4;
+      const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
+      int64_t rr[4];
+      bool ok[4];
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        const int row = (tid >> 3) + h * 64, kk = (tid & 7) * 4;
-        const bool ok = (m0 + row < p.M) && (k0 + kk < p.Kc);
-        const int64_t rr = (m0 + row < p.M) ? m0 + row : p.M - 1;
-        const int kc = (k0 + kk < p.Kc) ? k0 + kk : 0;
-        if (term == p.g_term) {
-          // tile row rr of the gathered term is compact row rr (hop tensors are never row-mapped)
-          const int e0 = p.g_rowptr[rr], e1 = p.g_rowptr[rr + 1];
-          if (e1 - e0 <= p.g_thresh) {
-            const float* __restrict__ Xg = p.g_X + (int64_t)bb * p.g_xbs + kc;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int e = e0; e < e1; e += 4) {
-              int c[4];
-              float w[4];
-              float4 xv[4];
+        const int row = (tid >> 3) + h * 64;
+        ok[h] = (m0 + row < p.M) && (k0 + kk < p.Kc);
+        rr[h] = (m0 + row < p.M) ? m0 + row : p.M - 1;
+      }
+      if (term == p.g_term) {
+        // this thread's 4 tile rows side by side, two stored entries each per step: 8 independent entry -> gather chains in flight.
+        // Rows above the threshold are read from memory like any other term (the hop launch wrote them).
+        int e[4], e1[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                c[u] = 0; w[u] = 0.f;
-                if (e + u < e1) { const tgcn_edge t = p.g_edges[e + u]; c[u] = t.col; w[u] = t.val; }
-              }
+        for (int h = 0; h < 4; ++h) { e[h] = p.g_rowptr[rr[h]]; e1[h] = p.g_rowptr[rr[h] + 1]; }      // tile row = compact row: hop tensors are never row-mapped
+        int len = 0;
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e + u < e1) xv[u] = *reinterpret_cast<const float4*>(Xg + (int64_t)c[u] * lda);
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (e + u < e1) {      // predicated, not multiplied by zero: Inf / NaN rows of X propagate as in hop_kernel
-                  s0 = fmaf(w[u], xv[u].x, s0); s1 = fmaf(w[u], xv[u].y, s1); s2 = fmaf(w[u], xv[u].z, s2); s3 = fmaf(w[u], xv[u].w, s3);
-                }
-            }
-            ra[h * 4 + 0] = ok ? s0 : 0.f; ra[h * 4 + 1] = ok ? s1 : 0.f; ra[h * 4 + 2] = ok ? s2 : 0.f; ra[h * 4 + 3] = ok ? s3 : 0.f;
-            continue;
+        for (int h = 0; h < 4; ++h) {
+          if (e1[h] - e[h] > p.g_thresh) {
+            const float4 v = *reinterpret_cast<const float4*>(A + rr[h] * lda + kc);
+            ra[h * 4 + 0] = v.x; ra[h * 4 + 1] = v.y; ra[h * 4 + 2] = v.z; ra[h * 4 + 3] = v.w;
+            e1[h] = e[h];
+          } else {
+            ra[h * 4 + 0] = ra[h * 4 + 1] = ra[h * 4 + 2] = ra[h * 4 + 3] = 0.f;
           }
+          len = max(len, e1[h] - e[h]);
         }
-        const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rr) * lda + kc);
-        ra[h * 4 + 0] = ok ? v.x : 0.f; ra[h * 4 + 1] = ok ? v.y : 0.f; ra[h * 4 + 2] = ok ? v.z : 0.f; ra[h * 4 + 3] = ok ? v.w : 0.f;
+        const float* __restrict__ Xg = p.g_X + (int64_t)bb * p.g_xbs + kc;
+        for (int j = 0; j < len; j += 2) {
+          int c[4][2];
+          float w[4][2];
+          float4 xv[4][2];
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              c[h][u] = 0; w[h][u] = 0.f;
+              if (e[h] + j + u < e1[h]) { const tgcn_edge t = p.g_edges[e[h] + j + u]; c[h][u] = t.col; w[h][u] = t.val; }
+            }
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              xv[h][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (e[h] + j + u < e1[h]) xv[h][u] = *reinterpret_cast<const float4*>(Xg + (int64_t)c[h][u] * lda);
+            }
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              if (e[h] + j + u < e1[h]) {      // predicated, not multiplied by zero: Inf / NaN rows of X propagate as in hop_kernel; stored order
+                ra[h * 4 + 0] = fmaf(w[h][u], xv[h][u].x, ra[h * 4 + 0]); ra[h * 4 + 1] = fmaf(w[h][u], xv[h][u].y, ra[h * 4 + 1]);
+                ra[h * 4 + 2] = fmaf(w[h][u], xv[h][u].z, ra[h * 4 + 2]); ra[h * 4 + 3] = fmaf(w[h][u], xv[h][u].w, ra[h * 4 + 3]);
+              }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (!ok[h]) ra[h * 4 + 0] = ra[h * 4 + 1] = ra[h * 4 + 2] = ra[h * 4 + 3] = 0.f;
+      } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rr[h]) * lda + kc);
+          ra[h * 4 + 0] = ok[h] ? v.x : 0.f; ra[h * 4 + 1] = ok[h] ? v.y : 0.f; ra[h * 4 + 2] = ok[h] ? v.z : 0.f; ra[h * 4 + 3] = ok[h] ? v.w : 0.f;
+        }
       }
     } else {      // thread = (row, k pair)
 #pragma unroll

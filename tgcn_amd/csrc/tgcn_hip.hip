@@ -53,7 +53,7 @@ int tgcn_abi_version(void) { return TGCN_ABI_VERSION; }
 
 void tgcn_reset_tuning(void) {
   g_hop_variant.store(0); g_hop_remap.store(1); g_hop_seg_remap.store(0); g_hop_mix.store(0); g_hop_stream.store(1); g_hop_lds_pad.store(0);
-  g_proj_variant.store(0); g_small_dense.store(2); g_small_narrow.store(1); g_x3_form.store(2); g_compact_proj.store(0); g_x3_tail.store(1); g_fuse_last.store(1);
+  g_proj_variant.store(0); g_small_dense.store(2); g_small_narrow.store(1); g_x3_form.store(2); g_compact_proj.store(0); g_x3_tail.store(1); g_fuse_last.store(0);
   g_overlap.store(0);
 }
 
@@ -902,8 +902,9 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
   int64_t a_bs[kMaxTerms];
   a_bs[0] = n * (int64_t)C;
   for (int k = 1; k < K; ++k) a_bs[k] = bs_c;
-  // last hop fused into the projection of the compact rows: where that projection is the bf16x3 kernel with <= 64 output columns
-  // (tgcn_set_tuning("fuse_last_hop", 0) keeps hop + projection; with compact_proj = 1 the projection runs over all vertices instead)
+  // tgcn_set_tuning("fuse_last_hop", 1): last hop fused into the projection of the compact rows, where that projection is the bf16x3 kernel
+  // with <= 64 output columns (with compact_proj = 1 the projection runs over all vertices instead).  Bitwise the unfused result; OFF by
+  // default: measured slower on cfg5
   const bool fuse_last = g_fuse_last.load() && !(compact_id && g_compact_proj.load() == 1) && ((uintptr_t)x & 15) == 0 &&
                          project_gather_fusable(n_c, C, N, K, true) && (N % 4 == 0) && (((uintptr_t)out & 15) == 0) &&
                          (!bias || ((uintptr_t)bias & 15) == 0);
