@@ -255,9 +255,11 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
  * vertex rowmap[m] -- its output row, its bias row, and its row in every term t whose bit t is set in `mapped_terms` (typically term 0 = x in
  * the caller's labels); the other terms (compact hop tensors) are read at row m.  nbatch samples share the tile rows: sample b reads term t
  * at a[t] + b * a_bs[t] floats and writes out + b * out_bs (a per-vertex bias row then reaches HBM once per pass).  a_bs: HOST array of
- * nterms strides (nullable for nbatch = 1).  M = number of mapped rows (one sample); n_vertices = rows of the bias / output per sample. */
+ * nterms strides (nullable for nbatch = 1).  M = number of mapped rows (one sample); n_vertices = rows of the bias / output per sample.
+ * interleave > 1 (vertex-major operands of the layout-1 driver, nbatch = 1): tile row m = (mapped vertex m / interleave, sample m % interleave),
+ * M = mapped vertices x interleave; a mapped term is read at row rowmap[v] * interleave + s, the output row is s * n_vertices + rowmap[v]. */
 int tgcn_cheb_project_mapped_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a, const int64_t* lda,
-                                 const float* W, const float* bias, int32_t bias_kind, int64_t n_vertices, const int32_t* rowmap,
+                                 const float* W, const float* bias, int32_t bias_kind, int64_t n_vertices, int64_t interleave, const int32_t* rowmap,
                                  uint32_t mapped_terms, int32_t nbatch, const int64_t* a_bs, int64_t out_bs, float* out, int64_t ldo);
 
 /* Streaming time windows (replaces materialising the T-H+1 overlapping windows of

@@ -331,13 +331,16 @@ def _directed_with_isolated(n, m, rng):
 
 
 @pytest.mark.parametrize("symmetric", [True, False], ids=["symmetric", "referenced-only-vertices"])
-@pytest.mark.parametrize("cls,q,f,g_out,K", [("ChebConv", 2, 16, 24, 5), ("ChebConv", 1, 64, 64, 3), ("ChebTimeConv", 2, 2, 8, 4), ("GCNCheb", 2, 32, 16, 5)])
+@pytest.mark.parametrize("cls,q,f,g_out,K", [("ChebConv", 2, 16, 24, 5), ("ChebConv", 1, 64, 64, 3), ("ChebTimeConv", 2, 2, 8, 4), ("GCNCheb", 2, 32, 16, 5),
+                                             ("GCNCheb", 16, 1, 64, 5), ("ChebConv", 5, 4, 8, 3)],      # the last two: vertex-major layout 1 (short per-sample rows, cfg5n's shape)
+                         ids=["ChebConv-q2-f16", "ChebConv-q1-f64", "ChebTimeConv-q2-f2", "GCNCheb-q2-f32", "GCNCheb-q16-f1-layout1", "ChebConv-q5-f4-layout1"])
 def test_compact_layers_equal_uncompacted_layers(cls, q, f, g_out, K, symmetric, gpu_device, monkeypatch):
     """Both recursions on a 70 k-vertex graph with isolated vertices (and, unsymmetric, vertices that entries point at but that have
     none of their own: for the Chebyshev recurrence those stay in the compact set, T_k of such a vertex is +-x, not 0): the compact
     forward / backward against the same module with compaction switched off, and the forward against the oracle."""
     import tgcn_amd
     from tgcn_amd import functional as F
+    monkeypatch.setattr(F, "COMPACT_LAYOUT1", True)       # the vertex-major form is built and tested, off by default (slower on cfg5n)
     rng = np.random.default_rng(K * 7 + f)
     n = 70_000
     u, v = _directed_with_isolated(n, 300_000, rng)
@@ -365,6 +368,7 @@ def test_compact_layers_equal_uncompacted_layers(cls, q, f, g_out, K, symmetric,
         op = layer._operand(_dev(x), ei, None)
         mode, plan = F.MODE_CHEBYSHEV, op.compact_plan("closed")
     assert plan is not None and plan.n_empty >= n // 8
+    assert F.choose_layout(q, n, x.reshape(q, n, -1).shape[2]) == (1 if (q > 1 and x.reshape(q, n, -1).shape[2] < 32) else 0)
     if mode == F.MODE_CHEBYSHEV and not symmetric:
         assert plan.n_c > op.compact_plan("rows").n_c          # referenced-only vertices are kept for the Chebyshev recurrence
     gout = rng.standard_normal((q, n, g_out)).astype(np.float32)

@@ -90,13 +90,17 @@ __device__ __forceinline__ void pooled_store(const ProjParams& p, const float* m
 constexpr uint32_t kProjMapTermsOnly = 0x80000000u;
 
 // row of term `term` that tile row m reads
+// (with interleave > 1 tile rows are (vertex v = m / interleave, sample m % interleave) and the map applies to the vertex)
 __device__ __forceinline__ int64_t proj_arow(const ProjParams& p, int term, int64_t m) {
-  return (p.rowmap && ((p.mapped >> term) & 1u)) ? (int64_t)p.rowmap[m] : m;
+  if (!(p.rowmap && ((p.mapped >> term) & 1u))) return m;
+  return (p.interleave == 1) ? (int64_t)p.rowmap[m] : (int64_t)p.rowmap[m / p.interleave] * p.interleave + m % p.interleave;
 }
-// output row of tile row m: the row map, or the layout-1 interleave (vertex-major tile rows -> sample-major output)
+// output row of tile row m: the row map, the layout-1 interleave (vertex-major tile rows -> sample-major output), or both
 __device__ __forceinline__ int64_t proj_orow(const ProjParams& p, int64_t m) {
-  if (p.rowmap && !(p.mapped & kProjMapTermsOnly)) return (int64_t)p.rowmap[m];
-  return (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+  const bool mapped = p.rowmap && !(p.mapped & kProjMapTermsOnly);
+  if (p.interleave == 1) return mapped ? (int64_t)p.rowmap[m] : m;
+  const int64_t v = m / p.interleave;
+  return (m % p.interleave) * p.n_vertices + (mapped ? (int64_t)p.rowmap[v] : v);
 }
 
 // float offset of row m of a term: plain row stride, or overlapping time windows of a (vertex, T) series
@@ -1141,12 +1145,12 @@ __global__ __launch_bounds__(kBlock) void project_narrow_kernel(const ProjParams
   const int nrows = (int)(mend - mb0);
   for (int i = threadIdx.x; i < ktot * p.N; i += kBlock) sW[i] = p.W[i];
   for (int t = 0; t < p.nterms; ++t) {
-    const float* __restrict__ at = p.a[t] + mb0 * p.lda[t];
+    const float* __restrict__ at = p.a[t];
     const int64_t ld = p.lda[t];
     for (int i = threadIdx.x; i < nrows * p.Kc; i += kBlock) {
       const int l = i / p.Kc, kc = i - l * p.Kc;                 // local row = (it * 4 + j) * RP + r
       const int it = l / (4 * RP), rem = l - it * 4 * RP, j = rem / RP, r = rem - j * RP;
-      sA[(((t * p.Kc + kc) * iters + it) * RP + r) * 4 + j] = at[(int64_t)l * ld + kc];
+      sA[(((t * p.Kc + kc) * iters + it) * RP + r) * 4 + j] = at[proj_arow(p, t, mb0 + l) * ld + kc];     // through the row map for mapped terms
     }
   }
   __syncthreads();

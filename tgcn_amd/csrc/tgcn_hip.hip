@@ -232,7 +232,8 @@ static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterm
     c.nts = best;
   }
   c.pool_epilogue = false;
-  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && !windows && !has_rowmap && vec_epilogue && N <= 1024 && (M >= 4096 || pv == 5)) {
+  (void)has_rowmap;     // every kernel reads mapped terms / writes mapped rows through proj_arow / proj_orow
+  if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && !windows && vec_epilogue && N <= 1024 && (M >= 4096 || pv == 5)) {
     c.kernel = kProjNarrow;           // a few scalars per row: the output streams from the vector ALU
     return c;
   }
@@ -271,11 +272,12 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
 }
 
 int tgcn_cheb_project_mapped_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a, const int64_t* lda,
-                                 const float* W, const float* bias, int32_t bias_kind, int64_t n_vertices, const int32_t* rowmap,
+                                 const float* W, const float* bias, int32_t bias_kind, int64_t n_vertices, int64_t interleave, const int32_t* rowmap,
                                  uint32_t mapped_terms, int32_t nbatch, const int64_t* a_bs, int64_t out_bs, float* out, int64_t ldo) {
-  if (!rowmap || nbatch < 1 || (nbatch > 1 && !a_bs) || (mapped_terms & kProjMapTermsOnly)) TGCN_FAIL(TGCN_ERR_INVALID, "project_mapped: bad argument");
+  if (!rowmap || nbatch < 1 || (nbatch > 1 && !a_bs) || (mapped_terms & kProjMapTermsOnly) || interleave < 1)
+    TGCN_FAIL(TGCN_ERR_INVALID, "project_mapped: bad argument");
   int64_t zero_bs[kMaxTerms] = {0};
-  return project_impl(stream, M, Kc, N, nterms, a, lda, W, bias, bias_kind, n_vertices, 1, 0, out, ldo, 0, 0, -1, rowmap, mapped_terms, nbatch,
+  return project_impl(stream, M, Kc, N, nterms, a, lda, W, bias, bias_kind, n_vertices, interleave, 0, out, ldo, 0, 0, -1, rowmap, mapped_terms, nbatch,
                       a_bs ? a_bs : zero_bs, out_bs);
 }
 
@@ -299,8 +301,10 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "project: bias_kind %d", bias_kind);
   if (interleave < 1 || n_vertices < 1) TGCN_FAIL(TGCN_ERR_INVALID, "project: interleave/n_vertices");
-  if (interleave > 1 && M != interleave * n_vertices) TGCN_FAIL(TGCN_ERR_INVALID, "project: M != interleave*n_vertices");
-  if (rowmap && (interleave != 1 || win_n != 0)) TGCN_FAIL(TGCN_ERR_INVALID, "project: a row map excludes interleave / windows");
+  if (interleave > 1 && !rowmap && M != interleave * n_vertices) TGCN_FAIL(TGCN_ERR_INVALID, "project: M != interleave*n_vertices");
+  if (rowmap && win_n != 0) TGCN_FAIL(TGCN_ERR_INVALID, "project: a row map excludes windows");
+  if (rowmap && interleave != 1 && (M % interleave != 0 || (mapped & kProjMapTermsOnly) || nbatch != 1))
+    TGCN_FAIL(TGCN_ERR_INVALID, "project: row map with interleave %lld: M must be mapped vertices x interleave, one sample batch", (long long)interleave);
   ProjParams p;
   memset(&p, 0, sizeof(p));
   p.rowmap = rowmap; p.mapped = rowmap ? mapped : 0u;

@@ -271,14 +271,20 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
     return out
 
 
+COMPACT_LAYOUT1 = False           # compact hop tensors for the vertex-major layout too: built and tested, measured on cfg5n (TGCNCheb(L,1,64,5), q = 16 on the
+                                  # 10 M-vertex R-MAT): hop 2.08 -> 2.08 ms (64-byte rows: the launch is bound by its 160 M line requests, not by the rows it
+                                  # writes), row-mapped projection 10.3 -> 12.2 ms (41 GB of output through a row map instead of one stream) => off
 COMPACT_SLAB_BYTES = 64 << 20    # a hop launch covers one sample when a sample's (n_c, C) slab is larger (the gather working set stays one slab)
 
 
 def compact_plan_for(op, mode, K, q, n, C_row):
     """The graph.CompactPlan a layer of this shape runs on, or None: square operands with enough vertices to leave out of the hop tensors
-    (graph.GraphOperand.compact_plan), 2 <= K <= 32, rows in the (q, n, C) layout.  Mode 0 keeps the rows with entries, mode 1 also every
-    referenced vertex (closed form T_k[i] = x[i], 0, -x[i], ... for the isolated rest)."""
-    if not COMPACT or not (2 <= K <= 32) or op.n != op.n_cols or choose_layout(q, n, C_row) != 0:
+    (graph.GraphOperand.compact_plan), 2 <= K <= 32; both row layouts (the vertex-major layout 1 of short per-sample rows runs its hops on
+    (n_c, q*C) rows).  Mode 0 keeps the rows with entries, mode 1 also every referenced vertex (closed form T_k[i] = x[i], 0, -x[i], ...
+    for the isolated rest)."""
+    if not COMPACT or not (2 <= K <= 32) or op.n != op.n_cols:
+        return None
+    if choose_layout(q, n, C_row) == 1 and not COMPACT_LAYOUT1:
         return None
     return op.compact_plan("rows" if mode == MODE_POWER else "closed")
 
@@ -343,21 +349,22 @@ def left_out_weight(W_kcn, mode):
     return (W_kcn * sign.view(K, 1, 1)).sum(0).contiguous()
 
 
-def project_mapped(terms, term_bs, W2d, bias, bias_kind, n_vertices, rowmap, mapped_terms, q, out):
+def project_mapped(terms, term_bs, W2d, bias, bias_kind, n_vertices, rowmap, mapped_terms, q, out, interleave=1):
     """out[b, rowmap[m]] = sum_t terms[t][b, row_t(m)] @ W[t] + bias through tgcn_cheb_project_mapped_f32; terms: tensors whose sample b starts
-    term_bs[t] floats after sample b-1; W2d: (T*Kc, N); out: (q, n_vertices, N) contiguous"""
+    term_bs[t] floats after sample b-1; W2d: (T*Kc, N); out: (q, n_vertices, N) contiguous.
+    interleave = q > 1: vertex-major terms ((rows, q, Kc): the samples of a vertex are consecutive rows), one launch for all samples."""
     L = _lib.lib()
     T = len(terms)
     Kc = W2d.shape[0] // T
     N = W2d.shape[1]
-    M = int(rowmap.numel())
+    M = int(rowmap.numel()) * interleave
     if M == 0:
         return out
     a = (C.c_void_p * T)(*[t.data_ptr() for t in terms])
     lda = (C.c_int64 * T)(*[Kc] * T)
     a_bs = (C.c_int64 * T)(*term_bs)
-    _lib.check(L.tgcn_cheb_project_mapped_f32(_lib.stream_ptr(), M, Kc, N, T, a, lda, _lib.ptr(W2d), _lib.ptr(bias), bias_kind, n_vertices,
-                                              _lib.ptr(rowmap), mapped_terms, q, a_bs, n_vertices * N, _lib.ptr(out), N))
+    _lib.check(L.tgcn_cheb_project_mapped_f32(_lib.stream_ptr(), M, Kc, N, T, a, lda, _lib.ptr(W2d), _lib.ptr(bias), bias_kind, n_vertices, interleave,
+                                              _lib.ptr(rowmap), mapped_terms, 1 if interleave > 1 else q, a_bs, n_vertices * N, _lib.ptr(out), N))
     return out
 
 
@@ -372,10 +379,22 @@ def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, terms=None):
     assert x3.is_contiguous() and n == plan.n and 2 <= K <= 32
     if x3.data_ptr() % 16:
         x3 = x3.clone()
+    b = bias.contiguous() if bias is not None else None
+    if choose_layout(q, n, Crow) == 1:
+        # short per-sample rows: one long row per vertex for the gathers, (n, q*C) -- the hop tensors are (n_c + 1, q*C), the projections read
+        # them as (vertex, sample) rows of C floats and write the sample-major output through the row map (interleave = q)
+        assert terms is None
+        xt = relayout_qnc_to_nqc(x3).view(1, n, q * Crow)
+        tt = compact_terms(plan, xt, K, mode)
+        out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
+        W2 = Wt_kcn.reshape(K * Crow, N).contiguous()
+        project_mapped(tt, [0] * K, W2, b, bias_kind, n, plan.rows, 1 if mode == MODE_POWER else 0, q, out, interleave=q)
+        if plan.n_empty:
+            project_mapped([xt], [0], left_out_weight(Wt_kcn, mode), b, bias_kind, n, plan.empty, 1, q, out, interleave=q)
+        return out, None
     if terms is None:
         terms = compact_terms(plan, x3, K, mode)
     out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
-    b = bias.contiguous() if bias is not None else None
     cbs = (plan.n_c + 1) * Crow
     if mode == MODE_POWER:        # term 0 = x through the row map, the others compact
         project_mapped(terms, [n * Crow] + [cbs] * (K - 1), Wt_kcn.reshape(K * Crow, N).contiguous(), b, bias_kind, n, plan.rows, 1, q, out)
@@ -578,7 +597,7 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     if use_project_first(x3.shape[0], x3.shape[1], Crow, N):
         return cheb_forward_pf(op, x3, Wt, b, bias_kind, mode)
     plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow)
-    if plan is not None and mode == MODE_POWER:            # many structurally empty rows: compact hop tensors, one call
+    if plan is not None and mode == MODE_POWER and choose_layout(x3.shape[0], x3.shape[1], Crow) == 0:   # many structurally empty rows: compact hop tensors, one call
         return cheb_forward_compact(plan, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, K)
     if plan is not None:                                   # the same for the Chebyshev recurrence (closed form for isolated vertices)
         return compact_forward(plan, x3, Wt, b, bias_kind, mode)[0]
@@ -636,7 +655,8 @@ class ChebLayerFn(torch.autograd.Function):
         # grad_mode: whether the CALLER records gradients (inside forward() grad mode is always off, and needs_input_grad only
         # mirrors requires_grad): an inference call under torch.no_grad() keeps nothing for a backward that never comes
         plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow) if general else None
-        if plan is not None and grad_mode and ctx.needs_input_grad[1] and K * x3.shape[0] * (plan.n_c + 1) * Crow * 4 <= KEEP_BASIS_BYTES:
+        lay0 = choose_layout(x3.shape[0], x3.shape[1], Crow) == 0
+        if plan is not None and lay0 and grad_mode and ctx.needs_input_grad[1] and K * x3.shape[0] * (plan.n_c + 1) * Crow * 4 <= KEEP_BASIS_BYTES:
             # training forward on an operand with left-out vertices: compact hop tensors, kept for the weight gradient
             Wt = fold_weight(fold, W) if fold is not None else W
             out, terms = compact_forward(plan, x3, Wt, b, bias_kind, mode)
