@@ -257,7 +257,8 @@ int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_
  * at a[t] + b * a_bs[t] floats and writes out + b * out_bs (a per-vertex bias row then reaches HBM once per pass).  a_bs: HOST array of
  * nterms strides (nullable for nbatch = 1).  M = number of mapped rows (one sample); n_vertices = rows of the bias / output per sample.
  * interleave > 1 (vertex-major operands of the layout-1 driver, nbatch = 1): tile row m = (mapped vertex m / interleave, sample m % interleave),
- * M = mapped vertices x interleave; a mapped term is read at row rowmap[v] * interleave + s, the output row is s * n_vertices + rowmap[v]. */
+ * M = mapped vertices x interleave; a mapped term is read at row rowmap[v] * interleave + s, the output row is s * n_vertices + rowmap[v].
+ * This form exists in the vector-ALU kernel only (nterms * Kc <= 16 scalars per row, N % 4 == 0, M >= 4096): TGCN_ERR_UNSUPPORTED otherwise. */
 int tgcn_cheb_project_mapped_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a, const int64_t* lda,
                                  const float* W, const float* bias, int32_t bias_kind, int64_t n_vertices, int64_t interleave, const int32_t* rowmap,
                                  uint32_t mapped_terms, int32_t nbatch, const int64_t* a_bs, int64_t out_bs, float* out, int64_t ldo);

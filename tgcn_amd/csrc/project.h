@@ -90,13 +90,22 @@ __device__ __forceinline__ void pooled_store(const ProjParams& p, const float* m
 constexpr uint32_t kProjMapTermsOnly = 0x80000000u;
 
 // row of term `term` that tile row m reads
-// (with interleave > 1 tile rows are (vertex v = m / interleave, sample m % interleave) and the map applies to the vertex)
 __device__ __forceinline__ int64_t proj_arow(const ProjParams& p, int term, int64_t m) {
+  return (p.rowmap && ((p.mapped >> term) & 1u)) ? (int64_t)p.rowmap[m] : m;
+}
+// output row of tile row m: the row map, or the layout-1 interleave (vertex-major tile rows -> sample-major output)
+__device__ __forceinline__ int64_t proj_orow(const ProjParams& p, int64_t m) {
+  if (p.rowmap && !(p.mapped & kProjMapTermsOnly)) return (int64_t)p.rowmap[m];
+  return (p.interleave == 1) ? m : (m % p.interleave) * p.n_vertices + m / p.interleave;
+}
+// Row map AND interleave together (vertex-major operands of a compacted layer: tile row m = (mapped vertex m / interleave, sample
+// m % interleave); the map applies to the vertex).  Only project_narrow_kernel takes this form: the 64-bit divisions cost the MFMA kernels
+// registers they do not have (project_x3_kernel<4, true>: 124 -> 138 VGPRs = one workgroup per CU instead of two, measured 44 -> 67 ms).
+__device__ __forceinline__ int64_t proj_arow_il(const ProjParams& p, int term, int64_t m) {
   if (!(p.rowmap && ((p.mapped >> term) & 1u))) return m;
   return (p.interleave == 1) ? (int64_t)p.rowmap[m] : (int64_t)p.rowmap[m / p.interleave] * p.interleave + m % p.interleave;
 }
-// output row of tile row m: the row map, the layout-1 interleave (vertex-major tile rows -> sample-major output), or both
-__device__ __forceinline__ int64_t proj_orow(const ProjParams& p, int64_t m) {
+__device__ __forceinline__ int64_t proj_orow_il(const ProjParams& p, int64_t m) {
   const bool mapped = p.rowmap && !(p.mapped & kProjMapTermsOnly);
   if (p.interleave == 1) return mapped ? (int64_t)p.rowmap[m] : m;
   const int64_t v = m / p.interleave;
@@ -1145,12 +1154,21 @@ __global__ __launch_bounds__(kBlock) void project_narrow_kernel(const ProjParams
   const int nrows = (int)(mend - mb0);
   for (int i = threadIdx.x; i < ktot * p.N; i += kBlock) sW[i] = p.W[i];
   for (int t = 0; t < p.nterms; ++t) {
-    const float* __restrict__ at = p.a[t];
     const int64_t ld = p.lda[t];
-    for (int i = threadIdx.x; i < nrows * p.Kc; i += kBlock) {
-      const int l = i / p.Kc, kc = i - l * p.Kc;                 // local row = (it * 4 + j) * RP + r
-      const int it = l / (4 * RP), rem = l - it * 4 * RP, j = rem / RP, r = rem - j * RP;
-      sA[(((t * p.Kc + kc) * iters + it) * RP + r) * 4 + j] = at[proj_arow(p, t, mb0 + l) * ld + kc];     // through the row map for mapped terms
+    if (p.rowmap && ((p.mapped >> t) & 1u)) {      // block-uniform: a mapped term (x of a compacted layer) is read through the row map
+      const float* __restrict__ at = p.a[t];
+      for (int i = threadIdx.x; i < nrows * p.Kc; i += kBlock) {
+        const int l = i / p.Kc, kc = i - l * p.Kc;
+        const int it = l / (4 * RP), rem = l - it * 4 * RP, j = rem / RP, r = rem - j * RP;
+        sA[(((t * p.Kc + kc) * iters + it) * RP + r) * 4 + j] = at[proj_arow_il(p, t, mb0 + l) * ld + kc];
+      }
+    } else {
+      const float* __restrict__ at = p.a[t] + mb0 * ld;
+      for (int i = threadIdx.x; i < nrows * p.Kc; i += kBlock) {
+        const int l = i / p.Kc, kc = i - l * p.Kc;                 // local row = (it * 4 + j) * RP + r
+        const int it = l / (4 * RP), rem = l - it * 4 * RP, j = rem / RP, r = rem - j * RP;
+        sA[(((t * p.Kc + kc) * iters + it) * RP + r) * 4 + j] = at[(int64_t)l * ld + kc];
+      }
     }
   }
   __syncthreads();
@@ -1178,7 +1196,7 @@ __global__ __launch_bounds__(kBlock) void project_narrow_kernel(const ProjParams
     for (int j = 0; j < 4; ++j) {
       const int64_t m = mb0 + (it * 4 + j) * RP + r_in;
       if (m >= mend) continue;
-      const int64_t orow = proj_orow(p, m);
+      const int64_t orow = p.rowmap ? proj_orow_il(p, m) : proj_orow(p, m);
       float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       if (p.bias_kind && c4 < p.bias_cols) {
         const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;

@@ -323,6 +323,8 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
                    (p.bias_cols % 4 == 0);
   const ProjChoice choice = project_choose(M, Kc, N, nterms, vec4, p.vec_epilogue != 0, rowmap != nullptr, win_n != 0);
+  if (rowmap && interleave != 1 && choice.kernel != kProjNarrow)
+    TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: a row map together with interleave is the vector-ALU kernel's form (nterms*Kc <= %d, N %% 4 == 0, M >= 4096)", kNarrowMaxK);
   if (pool > 1) {     // fused relu + max-pool epilogue: only where the dispatch takes a kernel that has it
     if (rowmap || interleave != 1 || accumulate || win_n != 0 || nbatch != 1 || pool < 2 || 16 % pool != 0 || M % pool != 0 || !choice.pool_epilogue)
       TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: no fused pool epilogue for this shape (M=%lld Kc=%d N=%d terms=%d pool=%d)", (long long)M, Kc, N, nterms, pool);

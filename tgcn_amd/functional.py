@@ -277,15 +277,15 @@ COMPACT_LAYOUT1 = False           # compact hop tensors for the vertex-major lay
 COMPACT_SLAB_BYTES = 64 << 20    # a hop launch covers one sample when a sample's (n_c, C) slab is larger (the gather working set stays one slab)
 
 
-def compact_plan_for(op, mode, K, q, n, C_row):
+def compact_plan_for(op, mode, K, q, n, C_row, N=None):
     """The graph.CompactPlan a layer of this shape runs on, or None: square operands with enough vertices to leave out of the hop tensors
     (graph.GraphOperand.compact_plan), 2 <= K <= 32; both row layouts (the vertex-major layout 1 of short per-sample rows runs its hops on
     (n_c, q*C) rows).  Mode 0 keeps the rows with entries, mode 1 also every referenced vertex (closed form T_k[i] = x[i], 0, -x[i], ...
     for the isolated rest)."""
     if not COMPACT or not (2 <= K <= 32) or op.n != op.n_cols:
         return None
-    if choose_layout(q, n, C_row) == 1 and not COMPACT_LAYOUT1:
-        return None
+    if choose_layout(q, n, C_row) == 1 and not (COMPACT_LAYOUT1 and N is not None and K * C_row <= 16 and N % 4 == 0 and N <= 1024 and n * q >= 1 << 16):
+        return None       # the vertex-major form needs the vector-ALU projection (row map + interleave: a few scalars per row)
     return op.compact_plan("rows" if mode == MODE_POWER else "closed")
 
 
@@ -596,7 +596,7 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     Wt = fold_weight(fold, W) if fold is not None else W
     if use_project_first(x3.shape[0], x3.shape[1], Crow, N):
         return cheb_forward_pf(op, x3, Wt, b, bias_kind, mode)
-    plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow)
+    plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow, N)
     if plan is not None and mode == MODE_POWER and choose_layout(x3.shape[0], x3.shape[1], Crow) == 0:   # many structurally empty rows: compact hop tensors, one call
         return cheb_forward_compact(plan, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, K)
     if plan is not None:                                   # the same for the Chebyshev recurrence (closed form for isolated vertices)
@@ -654,7 +654,7 @@ class ChebLayerFn(torch.autograd.Function):
         general = not small_path_tile(op, Crow, mode) and not use_project_first(x3.shape[0], x3.shape[1], Crow, N)
         # grad_mode: whether the CALLER records gradients (inside forward() grad mode is always off, and needs_input_grad only
         # mirrors requires_grad): an inference call under torch.no_grad() keeps nothing for a backward that never comes
-        plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow) if general else None
+        plan = compact_plan_for(op, mode, K, x3.shape[0], x3.shape[1], Crow, N) if general else None
         lay0 = choose_layout(x3.shape[0], x3.shape[1], Crow) == 0
         if plan is not None and lay0 and grad_mode and ctx.needs_input_grad[1] and K * x3.shape[0] * (plan.n_c + 1) * Crow * 4 <= KEEP_BASIS_BYTES:
             # training forward on an operand with left-out vertices: compact hop tensors, kept for the weight gradient
@@ -735,7 +735,7 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
     g2d = g.reshape(q * n, N)
     gx = gW = gb = None
     general = not small_path_tile(op, Crow, mode) and not use_project_first(q, n, Crow, N)
-    plan = compact_plan_for(op, mode, K, q, n, Crow) if general else None
+    plan = compact_plan_for(op, mode, K, q, n, Crow, N) if general else None
     if needs[1] and (plan is not None or (basis is not None and basis[0] == "compact")):
         # operand with left-out vertices: the basis exists (kept by the forward, or recomputed here) for the kept vertices only
         if basis is not None and basis[0] == "compact":
@@ -763,9 +763,9 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
     if needs[0] and small_path_tile(op.transpose(), N, mode):
         # small graphs: dx = sum_j (L^T)^j g W_j^T is the one-launch forward kernel on (L^T, g, W^T)
         gx = cheb_forward_small(op.transpose(), g, Wt.permute(0, 2, 1).contiguous(), None, None, BIAS_NONE, mode)
-    elif needs[0] and general and compact_plan_for(op.transpose(), mode, K, q, n, N) is not None:
+    elif needs[0] and general and compact_plan_for(op.transpose(), mode, K, q, n, N, Crow) is not None:
         # dx = sum_k T_k(L^T) g W_k^T IS the layer on (L^T, g, W^T): with left-out vertices in L^T it runs on compact hop tensors too
-        planT = compact_plan_for(op.transpose(), mode, K, q, n, N)
+        planT = compact_plan_for(op.transpose(), mode, K, q, n, N, Crow)
         WtT = Wt.permute(0, 2, 1).contiguous()                       # (K, N, C)
         if mode == MODE_POWER:
             gx = cheb_forward_compact(planT, g, WtT.reshape(K * N, Crow), None, BIAS_NONE, K)
@@ -821,7 +821,7 @@ class ChebReluPoolFn(torch.autograd.Function):
                                                           _lib.ptr(W), _lib.ptr(fold), _lib.ptr(b), bias_kind, 1, pool,
                                                           _lib.ptr(z), _lib.ptr(idx)))
         elif (not small_path_tile(op, Crow, mode) and not use_project_first(q, n, Crow, N)
-              and compact_plan_for(op, mode, K, q, n, Crow) is None):
+              and compact_plan_for(op, mode, K, q, n, Crow, N) is None):
             # hops-then-projection path: bias + relu + max over `pool` vertices inside the projection's epilogue where the shape allows
             # (tgcn_cheb_forward_pool_f32: the (q, n, N) layer output is then never written), one extra pass over scratch otherwise
             Wt = fold_weight(fold, W) if fold is not None else W
