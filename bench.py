@@ -335,17 +335,25 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
                     left = agree(usable - (time.perf_counter() - t_start), dist.ReduceOp.MIN)
                     share = max(left, 0.0) / max(1, n_entries - (2 * mi + fi))
                     qs = int(max(1, min(qg, share / ((steps + 1.5) * max(t1, 1e-6)))))
-                    t0 = time.perf_counter()
-                    for _ in range(steps):
+                    # a transport on which even ONE time step eats the share (gloo through the host in rehearsals; a slow first contact with
+                    # RCCL): fewer forwards -- one measured step, and below that the timed one-step forward above IS the measurement
+                    if share < 2.5 * t1:
+                        steps, dt, qs, phases = 1, t1, 1, None
+                    else:
+                        if share < (steps + 1.5) * t1:
+                            steps = 1
+                        t0 = time.perf_counter()
+                        for _ in range(steps):
+                            fwd(overlap, qs)
+                        sync_all()
+                        dt = time.perf_counter() - t0
+                        sh.collect_stats = True                # one more forward with the phase log (device events add their own syncs)
                         fwd(overlap, qs)
-                    sync_all()
-                    dt = time.perf_counter() - t0
-                    sh.collect_stats = True                # one more forward with the phase log (device events add their own syncs)
-                    fwd(overlap, qs)
-                    sync_all()
-                    sh.collect_stats = False
-                dt = agree(dt, dist.ReduceOp.MAX)
-                mine = dict(sh.describe(), phases_ms=sh.stats)
+                        sync_all()
+                        sh.collect_stats = False
+                        phases = sh.stats
+                        dt = agree(dt, dist.ReduceOp.MAX)
+                mine = dict(sh.describe(), phases_ms=phases)
                 per_rank = [None] * world
                 dist.all_gather_object(per_rank, mine)
                 C_in = spec["H"] * spec["f"]
@@ -551,6 +559,11 @@ def main():
         roofline["physical_frac"] = round(phys / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         roofline["physical_note"] = ("entries + row pointers + each of the %d rows that exist in the hop tensors once in and once out; the entry stream is "
                                      "read by every launch" % n_rows)
+        if not hop_long_ms and n_hop_launches % max(1, K - 1) == 0 and K > 2:
+            # mean launch time by hop position (hop 1 gathers from x in the caller's labels, the others from compact hop tensors): the launches of a
+            # time step follow each other in hop order on every path of the layer driver
+            per = np.array(hop_ms[: (len(hop_ms) // (K - 1)) * (K - 1)]).reshape(-1, K - 1).mean(axis=0)
+            roofline["mean_launch_ms_by_hop"] = [round(float(v), 4) for v in per]
         if hop_long_ms:
             roofline["note"] = ("last hop fused into the projection: %d of the %d hop launches per step cover the rows above the threshold only and are NOT in "
                                 "mean_launch_ms; frac is for the full hop launches" % (len(hop_long_ms) // args.steps, n_hop_launches))
