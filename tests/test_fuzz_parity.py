@@ -146,3 +146,24 @@ def test_random_module_vs_oracle(case, gpu_device):
     if case["bias"]:
         gb = go.double().sum(dim=(0, 1)) if layer.bias.numel() == g else go.double().sum(dim=0)
         assert rel_err(layer.bias.grad.cpu().numpy().reshape(-1), gb.cpu().numpy().reshape(-1)) <= gtol
+
+
+def test_random_modules_on_compact_hop_tensors(gpu_device, monkeypatch):
+    """The same random cases (five classes, vertex 0 isolated in every graph, hubs, K = 1 ... 8, widths 1 ... 640) with the general path
+    FORCED onto compact hop tensors -- every layout (incl. the vertex-major form that is off by default), both recursions, the one-call driver
+    and the python-level pipeline, with the last hop fused into the projection where that form exists -- against the oracle."""
+    from tgcn_amd import functional as F, graph, _lib
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    monkeypatch.setattr(graph, "COMPACT_MIN_EMPTY", 0.0)
+    monkeypatch.setattr(F, "SMALL_PATH", False)
+    monkeypatch.setattr(F, "PROJECT_FIRST", False)
+    monkeypatch.setattr(F, "COMPACT_LAYOUT1", True)
+    used = {"drv": 0, "py": 0}
+    real_drv, real_py = F.cheb_forward_compact, F.compact_forward
+    monkeypatch.setattr(F, "cheb_forward_compact", lambda *a, **k: (used.__setitem__("drv", used["drv"] + 1), real_drv(*a, **k))[1])
+    monkeypatch.setattr(F, "compact_forward", lambda *a, **k: (used.__setitem__("py", used["py"] + 1), real_py(*a, **k))[1])
+    for fuse in (0, 1):
+        _lib.check(_lib.lib().tgcn_set_tuning(b"fuse_last_hop", fuse))
+        for case in CASES[:40]:
+            _check_forward(case)
+    assert used["drv"] >= 10 and used["py"] >= 10, used

@@ -63,9 +63,13 @@ def resolve(name, names):
     return None
 
 
+SCRIPT = os.path.join(ROOT, "tools", "hop_bench.py")      # the program profiled (--script)
+KERNELS = ["hop_fixup_kernel", "hop_kernel"]               # substrings of the kernel names folded (--kernels; first match wins)
+
+
 def run_pass(counters, out_dir, tag, bench_args, limit):
     d = os.path.join(out_dir, tag)
-    cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "hop_bench.py")] + bench_args
+    cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, SCRIPT] + bench_args
     t0 = time.time()
     with open(d + ".log", "w") as log:
         log.write(" ".join(cmd) + "\n")
@@ -78,8 +82,7 @@ def run_pass(counters, out_dir, tag, bench_args, limit):
     rows = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"]
-            k = "hop_fixup_kernel" if "hop_fixup_kernel" in k else "hop_kernel" if "hop_kernel" in k else None
+            k = next((name for name in KERNELS if name in r["Kernel_Name"]), None)
             if k:
                 rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     shutil.rmtree(d, ignore_errors=True)        # raw rocprofv3 output: tens of MB per pass, gpurun merges at most 64 MiB back
@@ -89,7 +92,7 @@ def run_pass(counters, out_dir, tag, bench_args, limit):
 
 def collect(counters, out_dir, tag, bench_args, limit, acc, failed):
     rc, rows = run_pass(counters, out_dir, tag, bench_args, limit)
-    got = set(rows.get("hop_kernel", {}))
+    got = set(rows.get(KERNELS[-1], {}))
     if got:
         for k, cs in rows.items():
             for c, v in cs.items():
@@ -154,14 +157,21 @@ def main():
     ap.add_argument("--only-blocks", default="")
     ap.add_argument("--limit", type=int, default=300, help="seconds per pass")
     ap.add_argument("--max-passes", type=int, default=99, help="stop after this many combined passes per labeling")
+    ap.add_argument("--script", default=None, help="program to profile instead of tools/hop_bench.py (e.g. bench.py); --extra then holds ALL its arguments")
+    ap.add_argument("--kernels", default=None, help="comma list of kernel-name substrings to fold (first match wins; the LAST one is the kernel of interest)")
     args = ap.parse_args()
+    global SCRIPT, KERNELS
+    if args.script:
+        SCRIPT = os.path.join(ROOT, args.script)
+    if args.kernels:
+        KERNELS = args.kernels.split(",")
     out_dir = os.path.join(ROOT, "gpurun_out", args.tag)
     os.makedirs(out_dir, exist_ok=True)
     names = available(out_dir)
     print("%d counter names on this box" % len(names), flush=True)
     blocks = [b for b in CANDIDATES if not args.only_blocks or b in args.only_blocks.split(",")]
     for lab in args.labelings.split(","):
-        bench_args = ["--compact", "--variants", "0", "--rounds", "2", "--labeling", lab] + args.extra.split()
+        bench_args = (["--compact", "--variants", "0", "--rounds", "2", "--labeling", lab] if not args.script else ["--labeling", lab]) + args.extra.split()
         acc = collections.defaultdict(dict)
         failed, absent = [], []
         groups = {}
@@ -180,7 +190,7 @@ def main():
             parts = [(b, groups[b][i]) for b in blocks if i < len(groups[b])]
             combined = [c for _, g in parts for c in g]
             rc, rows = run_pass(combined, out_dir, "%s_p%d" % (lab, i), bench_args, args.limit)
-            got = set(rows.get("hop_kernel", {}))
+            got = set(rows.get(KERNELS[-1], {}))
             for k, cs in rows.items():
                 for c, v in cs.items():
                     acc[k][c] = (sum(v) / len(v), len(v))
@@ -189,14 +199,14 @@ def main():
                     collect(g, out_dir, "%s_p%d_%s" % (lab, i, b.lower()), bench_args, args.limit, acc, failed)
             else:
                 failed.extend(c for c in combined if c not in got)
-        res = dict(labeling=lab, command="rocprofv3 --pmc <counters> -- python3 tools/hop_bench.py " + " ".join(bench_args),
-                   note="mean per dispatch over the hop_kernel launches of the run (summed over the block's instances where the name ends in _sum); "
+        res = dict(labeling=lab, command="rocprofv3 --pmc <counters> -- python3 %s " % os.path.relpath(SCRIPT, ROOT) + " ".join(bench_args),
+                   note="mean per dispatch over the launches of each kernel in the run (summed over the block's instances where the name ends in _sum); "
                         "kernels run serialised under the profiler",
                    counters_absent_on_this_box=absent, counters_that_did_not_collect=failed,
-                   hop_kernel={c: v[0] for c, v in sorted(acc.get("hop_kernel", {}).items())},
-                   hop_kernel_dispatches={c: v[1] for c, v in sorted(acc.get("hop_kernel", {}).items())},
-                   hop_fixup_kernel={c: v[0] for c, v in sorted(acc.get("hop_fixup_kernel", {}).items())},
-                   derived=derived(acc.get("hop_kernel", {})))
+                   derived=derived(acc.get(KERNELS[-1], {})), derived_for=KERNELS[-1])
+        for kname in KERNELS:
+            res[kname] = {c: v[0] for c, v in sorted(acc.get(kname, {}).items())}
+            res[kname + "_dispatches"] = {c: v[1] for c, v in sorted(acc.get(kname, {}).items())}
         path = os.path.join(out_dir, "limiter_%s.json" % lab)
         json.dump(res, open(path, "w"), indent=1)
         print(open(path).read(), flush=True)
