@@ -391,6 +391,14 @@ int tgcn_cheb_forward_pool_f32(void* stream, const tgcn_csr* A, const tgcn_csr_s
 int tgcn_relu_pool_bwd_f32(void* stream, const float* grad_z, const float* z, const uint8_t* idx, float* grad_y, int64_t q,
                            int64_t n, int32_t f, int32_t p);
 
+/* Gradient of a hop w.r.t. the VALUES of its sparse operand (ABI v5): the sampled dense-dense product over the stored pattern
+ *   dval[e] (+)= alpha * sum_b sum_c rows[b, row(e), c] * cols[b, col(e), c]      for every stored entry e, in CSR order
+ * -- for S = L X: dL/dval_e = <dL/dS[row(e)], X[col(e)]>.  What makes `edge_weight` of ChebConv / ChebTimeConv and `value` of spmm* learnable as
+ * in the reference, whose gather / scale / scatter_add form is differentiable in them (tgcn/nn/gcn.py:296-308, 413, 510).  rows: (nb, A->n, C),
+ * cols: (nb, n_cols, C); one lane group per entry, fixed summation order (no atomics); accumulate != 0 adds to dval. */
+int tgcn_csr_sddmm_f32(void* stream, const tgcn_csr* A, int64_t n_cols, int32_t nb, int32_t C, const tgcn_dense* rows, const tgcn_dense* cols,
+                       float alpha, float* dval, int32_t accumulate);
+
 /* Vertex sharding (replaces nn.DataParallel's batch split, examples/pytorch_based/pytorch_hcp_tgcn.py:270-273):
  * out[i, 0:C] = src[idx[i], 0:C] -- the rows of a hop tensor that a neighbouring shard needs, packed into one message.
  * idx: int64 device array; src rows ld_src floats apart; out contiguous. */

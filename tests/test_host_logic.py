@@ -362,18 +362,19 @@ def test_operand_cache_evicts_least_recently_used_only():
     assert built == list(range(17)) + [1] and 2 not in cache._d
 
 
-def test_learnable_operand_values_are_refused_not_ignored():
-    """Reference: lap = -deg[row] * edge_weight * deg[col] and spmm's `value` are differentiable (tgcn/nn/gcn.py:413,510,296-308); here the
-    operand is packed outside autograd, so a weight that requires grad raises instead of silently getting no gradient."""
+def test_learnable_operand_values_are_never_silently_ignored():
+    """Reference: lap = -deg[row] * edge_weight * deg[col] and spmm's `value` are differentiable (tgcn/nn/gcn.py:413,510,296-308).  The MODULES
+    and spmm* carry that gradient (tests/test_values_grad.py, GPU); the low-level operand builder, which packs values outside autograd,
+    refuses a weight that requires grad instead of dropping its gradient."""
     import tgcn_amd
     from tgcn_amd import _lib
     ei = torch.tensor([[0, 1, 2], [1, 2, 0]])
     w = torch.ones(3, requires_grad=True)
     with pytest.raises(_lib.TgcnError, match="requires_grad"):
         tgcn_amd.GraphOperand.from_edge_index(ei, w, 3)
-    with pytest.raises(_lib.TgcnError, match="requires_grad"):
-        tgcn_amd.spmm(ei, w, 3, torch.ones(3, 2))
     assert tgcn_amd.GraphOperand.from_edge_index(ei, w.detach(), 3).nnz == 3      # detached weights build (CPU tensors: the torch form)
+    with pytest.raises(_lib.TgcnError, match="ROCm device"):                       # no CPU fallback for the differentiable ops either
+        tgcn_amd.spmm(ei, w, 3, torch.ones(3, 2))
 
 
 def test_operand_cache_is_thread_safe():

@@ -55,6 +55,8 @@ SIGNATURES = {
     "tgcn_profile_stop": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "tgcn_set_tuning": (C.c_int, [C.c_char_p, C.c_int32]),
     "tgcn_reset_tuning": (None, []),
+    "tgcn_csr_sddmm_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.c_int64, C.c_int32, C.c_int32, C.POINTER(DenseStruct), C.POINTER(DenseStruct), C.c_float, _P,
+                                     C.c_int32]),
     "tgcn_cheb_project_mapped_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int64, _P, C.c_uint32,
                                                 C.c_int32, _P, C.c_int64, _P, C.c_int64]),
     "tgcn_edge_normalise_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),

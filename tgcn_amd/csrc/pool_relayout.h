@@ -111,6 +111,42 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const float* __restri
   }
 }
 
+// Sampled dense-dense product over the stored pattern: the gradient of a hop w.r.t. its operand VALUES (tgcn/nn/gcn.py:296-308, 413, 510: the
+// reference's gather / scale / scatter_add form is differentiable in `value` / `edge_weight`):
+//   dval[e] (+)= alpha * sum_b sum_c A[b, row(e), c] * B[b, col(e), c]          for every stored entry e
+// One 16-lane group per entry (balanced on power-law graphs: no row is a unit of work); the group finds its row by binary search in the row
+// pointers, walks the C channels 64 at a time (one float4 per lane) over all nb samples, and folds through a fixed shuffle tree: one writer
+// per entry, no atomics, the same bits every run.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void sddmm_kernel(int64_t n, int64_t nnz, const int32_t* __restrict__ rowptr, const tgcn_edge* __restrict__ ev,
+                                                       int32_t nb, int32_t C, const float* __restrict__ A, int64_t a_bs, int64_t a_ld,
+                                                       const float* __restrict__ B, int64_t b_bs, int64_t b_ld, float alpha,
+                                                       float* __restrict__ dval, int accumulate) {
+  const int t = threadIdx.x & 15;
+  const int64_t groups = (int64_t)gridDim.x * (kBlock / 16);
+  for (int64_t e = (int64_t)blockIdx.x * (kBlock / 16) + (threadIdx.x >> 4); e < nnz; e += groups) {
+    int64_t lo = 0, hi = n;                               // row of entry e: the last r with rowptr[r] <= e
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)rowptr[mid] <= e) lo = mid; else hi = mid; }
+    const int64_t r = lo, c = ev[e].col;
+    float acc = 0.f;
+    for (int32_t b = 0; b < nb; ++b) {
+      const float* __restrict__ ar = A + (int64_t)b * a_bs + r * a_ld;
+      const float* __restrict__ br = B + (int64_t)b * b_bs + c * b_ld;
+      for (int32_t k = t * VEC; k < C; k += 16 * VEC) {
+        if constexpr (VEC == 4) {
+          const float4 x = *reinterpret_cast<const float4*>(ar + k), y = *reinterpret_cast<const float4*>(br + k);
+          acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        } else {
+          acc = fmaf(ar[k], br[k], acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+    if (t == 0) dval[e] = accumulate ? fmaf(alpha, acc, dval[e]) : alpha * acc;
+  }
+}
+
 // fp64 hop for the numpy twin gcn.graph.chebyshev with float64 operands (the reference computes in L.dtype, gcn/graph.py:247,
 // 256-265): S = L X; P = S (optional); Y = alpha S + beta Z.  One thread per output element, entries in stored order
 // (deterministic); these calls are small (M ~ 1e3 rows, N ~ batch columns), so no schedule.

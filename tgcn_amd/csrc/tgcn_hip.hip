@@ -1090,6 +1090,21 @@ int tgcn_csr_hop_f64(void* stream, int64_t n, const int32_t* rowptr, const int32
   return TGCN_OK;
 }
 
+int tgcn_csr_sddmm_f32(void* stream, const tgcn_csr* A, int64_t n_cols, int32_t nb, int32_t C, const tgcn_dense* rows, const tgcn_dense* cols,
+                       float alpha, float* dval, int32_t accumulate) {
+  if (!A || !rows || !cols || !rows->ptr || !cols->ptr || !dval || nb < 1 || C < 1 || n_cols < 1 || !A->rowptr || (A->nnz > 0 && !A->edges))
+    TGCN_FAIL(TGCN_ERR_INVALID, "sddmm: bad argument");
+  if (A->nnz == 0) return TGCN_OK;
+  const bool v4 = (C % 4 == 0) && aligned4(rows) && aligned4(cols);
+  const unsigned grid = grid_1d(A->nnz * 16);
+  if (v4) hipLaunchKernelGGL((sddmm_kernel<4>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, A->n, A->nnz, A->rowptr, A->edges, nb, C, rows->ptr,
+                             rows->batch_stride, rows->row_stride, cols->ptr, cols->batch_stride, cols->row_stride, alpha, dval, (int)accumulate);
+  else hipLaunchKernelGGL((sddmm_kernel<1>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, A->n, A->nnz, A->rowptr, A->edges, nb, C, rows->ptr,
+                          rows->batch_stride, rows->row_stride, cols->ptr, cols->batch_stride, cols->row_stride, alpha, dval, (int)accumulate);
+  TGCN_CHECK_LAUNCH("tgcn_csr_sddmm_f32");
+  return TGCN_OK;
+}
+
 int tgcn_pack_rows_f32(void* stream, const float* src, int64_t ld_src, const int64_t* idx, int64_t nrows, int32_t C, float* out) {
   if (!src || !idx || !out || nrows < 0 || C <= 0 || ld_src < C) TGCN_FAIL(TGCN_ERR_INVALID, "pack_rows: bad argument");
   if (nrows == 0) return TGCN_OK;

@@ -90,6 +90,65 @@ def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
     return out
 
 
+def csr_sddmm(op, rows3, cols3, alpha=1.0, out=None, accumulate=False):
+    """dval[e] (+)= alpha * sum_b sum_c rows3[b, row(e), c] * cols3[b, col(e), c] over the stored entries of `op`, in CSR order -> (nnz,).
+    The gradient of S = L X w.r.t. the values of L is csr_sddmm(op, dS, X) (tgcn_csr_sddmm_f32)."""
+    _lib.require_device(rows3, cols3, out)
+    nb, _, Crow = rows3.shape
+    assert rows3.shape[1] == op.n and cols3.shape[1] == op.n_cols and cols3.shape[0] == nb and cols3.shape[2] == Crow
+    if out is None:
+        out = torch.zeros(max(op.nnz, 1), dtype=torch.float32, device=rows3.device)[: op.nnz]
+        accumulate = False
+    R, Cc = _dense(rows3), _dense(cols3)
+    _lib.check(_lib.lib().tgcn_csr_sddmm_f32(_lib.stream_ptr(), C.byref(op.struct), op.n_cols, nb, Crow, C.byref(R), C.byref(Cc), float(alpha),
+                                             _lib.ptr(out), 1 if accumulate else 0))
+    return out
+
+
+class SpmmFn(torch.autograd.Function):
+    """out = L matrix3 (one hop) as a differentiable op: d matrix = L^T g (the hop on the cached transposed operand), d values = the sampled
+    product <g[row(e)], matrix[col(e)]> in CSR order (csr_sddmm) -- the reference's spmm* are differentiable in both (gcn.py:296-308)."""
+
+    @staticmethod
+    def forward(ctx, matrix3, values_csr, op):
+        ctx.op = op
+        ctx.save_for_backward(matrix3)
+        return csr_hop(op, matrix3)
+
+    @staticmethod
+    def backward(ctx, g):
+        (matrix3,) = ctx.saved_tensors
+        g = g.contiguous()
+        gm = csr_hop(ctx.op.transpose(), g) if ctx.needs_input_grad[0] else None
+        gv = csr_sddmm(ctx.op, g, matrix3) if ctx.needs_input_grad[1] else None
+        return gm, gv, None
+
+
+def chebyshev_values_grad(op, x3, W_kcn, g):
+    """d loss / d values (CSR order) of the true-recurrence layer out = sum_k T_k W_k, T_1 = L x, T_k = 2 L T_{k-1} - T_{k-2} (ChebConv /
+    ChebTimeConv: lap_e = -deg^-1/2[row] w_e deg^-1/2[col] is differentiable in w_e in the reference, tgcn/nn/gcn.py:413,510).
+    With G_k = g W_k^T and the Clenshaw adjoints b_{K-1} = G_{K-1}, b_k = G_k + 2 L^T b_{k+1} - b_{k+2}:
+        dL = b_1 T_0^T + 2 sum_{k>=2} b_k T_{k-1}^T   sampled on the stored pattern (csr_sddmm).  Hops, projection and SDDMM in libtgcn_hip.so."""
+    K, Crow, N = W_kcn.shape
+    q, n, _ = x3.shape
+    dval = torch.zeros(max(op.nnz, 1), dtype=torch.float32, device=x3.device)[: op.nnz]
+    if K < 2 or op.nnz == 0:
+        return dval
+    T = cheb_stack(op, x3.contiguous(), K - 1, MODE_CHEBYSHEV) if K > 2 else x3.contiguous().unsqueeze(0)      # T_0 .. T_{K-2}
+    g = g.contiguous()
+    Wcat = W_kcn.permute(2, 0, 1).reshape(1, N, K * Crow).contiguous()
+    Gall = cheb_project([g.reshape(q * n, N)], Wcat, None, BIAS_NONE, n).view(q, n, K * Crow)
+    G = [Gall[:, :, k * Crow:(k + 1) * Crow] for k in range(K)]
+    opT = op.transpose()
+    b = {K - 1: G[K - 1]}
+    for k in range(K - 2, 0, -1):
+        b[k] = csr_hop(opT, b[k + 1], z=b.get(k + 2), alpha=2.0, beta=-1.0, z2=G[k], gamma=1.0)
+    csr_sddmm(op, b[1], T[0], alpha=1.0, out=dval, accumulate=False)
+    for k in range(2, K):
+        csr_sddmm(op, b[k], T[k - 1], alpha=2.0, out=dval, accumulate=True)
+    return dval
+
+
 def _windows_forward(op, x3, W, bias, bias_kind, mode):
     """x3 (S, n, T) fp32 contiguous, W (K, H, N) in the WORKING basis (folded for MODE_POWER) -> (out, stack (K, S, n, T))"""
     L = _lib.lib()
@@ -644,7 +703,11 @@ class ChebLayerFn(torch.autograd.Function):
     small-graph path, by tgcn_fold_weight_f32 otherwise; backward applies the transposed fold to the weight gradient."""
 
     @staticmethod
-    def forward(ctx, x3, W, bias, op, mode, bias_kind, grad_mode=True):
+    def forward(ctx, x3, W, bias, op, mode, bias_kind, grad_mode=True, values=None):
+        # `values`: the operand's stored values in CSR order as a tensor of the autograd graph (learnable edge weights of ChebConv /
+        # ChebTimeConv).  The forward computes with the values packed in `op` (equal by construction); the tensor only receives the gradient.
+        if values is not None and (mode != MODE_CHEBYSHEV or op.perm is not None or values.numel() != op.nnz):
+            raise _lib.TgcnError("learnable operand values: Chebyshev-recurrence layers on an operand in the caller's labels only")
         K, Crow, N = W.shape
         x3 = x3.contiguous()
         W = W.contiguous()
@@ -678,7 +741,8 @@ class ChebLayerFn(torch.autograd.Function):
         gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad,
                                     basis=ctx.basis)
         ctx.basis = None
-        return gx, gW, gb, None, None, None, None
+        gv = chebyshev_values_grad(ctx.op, x3, W, g) if (len(ctx.needs_input_grad) > 7 and ctx.needs_input_grad[7]) else None
+        return gx, gW, gb, None, None, None, None, gv
 
 
 def _monomial_stack(op, x3, K):
@@ -712,11 +776,12 @@ def _to_operand_labels(op, x3, bias, bias_kind):
     return x3, bias
 
 
-def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode):
-    """Differentiable fused layer; weight_kcn: (K, C, N) in the reference basis."""
+def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode, values=None):
+    """Differentiable fused layer; weight_kcn: (K, C, N) in the reference basis.  values: the operand's values (CSR order) as an autograd
+    tensor when they are learnable (nn._EdgeBase builds it from edge_weight)."""
     x3, weight_kcn = _pad_rows(op, x3, weight_kcn, mode)
     x3, bias = _to_operand_labels(op, x3, bias, bias_kind)
-    out = ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind, torch.is_grad_enabled())
+    out = ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind, torch.is_grad_enabled(), values)
     return out if op.perm is None else out.index_select(1, op.inv_perm)
 
 

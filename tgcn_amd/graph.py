@@ -401,9 +401,9 @@ class GraphOperand:
         deg^-1/2 = 0 for isolated vertices."""
         device = edge_index.device if device is None else torch.device(device)
         if edge_weight is not None and edge_weight.requires_grad:
-            raise _lib.TgcnError("edge_weight.requires_grad: the operand is built outside autograd (kernels of the library), so the weight would "
-                                 "silently get no gradient -- detach() it, or keep the reference's modules for learnable edge weights "
-                                 "(lap = -deg[row] * edge_weight * deg[col], tgcn/nn/gcn.py:413,510)")
+            raise _lib.TgcnError("edge_weight.requires_grad: a GraphOperand is packed outside autograd, so the weight would silently get no gradient "
+                                 "from it -- pass the weight to ChebConv / ChebTimeConv instead (their forward carries d loss / d edge_weight, "
+                                 "lap = -deg[row] * edge_weight * deg[col], tgcn/nn/gcn.py:413,510), or detach() it here")
         if BUILDER == "library" and device.type == "cuda":
             return GraphOperand._from_edge_index_library(edge_index, edge_weight, int(n), device)
         # cross-check form (and CPU rehearsals): the same steps with torch index ops

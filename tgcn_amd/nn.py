@@ -222,13 +222,27 @@ _spmm_ops = _OperandCache()
 def _coo_operand(index, value, m, device, n_cols=None):
     """m x n_cols operand: the reference's gather / scatter_add form takes any number of source rows (gcn.py:296-308)."""
     n_cols = int(m if n_cols is None else n_cols)
-    if value is not None and value.requires_grad:
-        raise _lib.TgcnError("spmm: value.requires_grad -- the sparse operand is built outside autograd (packed CSR in the library), so the values would "
-                             "silently get no gradient; detach() them, or use the reference's gather / scatter_add form for learnable values "
-                             "(tgcn/nn/gcn.py:296-308)")
     key = (_tensor_key(index), _tensor_key(value), int(m), n_cols, str(device))
-    return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value, device, n_cols=n_cols),
+    return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value.detach(), device, n_cols=n_cols),
                          sources=(index, value))
+
+
+def _coo_values(index, value, op):
+    """`value` in the operand's CSR order as a tensor of the autograd graph (None when it needs no gradient): entries sorted by (row, col),
+    duplicates in their given order -- the order GraphOperand.from_coo packs (tests/test_device_build.py pins the two builders to it)."""
+    if value is None or not value.requires_grad:
+        return None
+    key = ("order", _tensor_key(index), op.n, op.n_cols, str(op.device))
+    order = _spmm_ops.get(key, lambda: torch.argsort(index[0].to(op.device).long() * max(op.n, op.n_cols) + index[1].to(op.device).long(), stable=True),
+                          sources=(index,))
+    return value.to(device=op.device, dtype=torch.float32).reshape(-1)[order]
+
+
+def _spmm3(op, x3, values):
+    """one hop, differentiable in the matrix and (when given) in the operand's values"""
+    if values is None and not x3.requires_grad:
+        return F.csr_hop(op, x3)
+    return F.SpmmFn.apply(x3, values, op)
 
 
 def spmm(index, value, m, matrix):
@@ -236,7 +250,7 @@ def spmm(index, value, m, matrix):
     matrix = matrix if matrix.dim() > 1 else matrix.unsqueeze(-1)
     op = _coo_operand(index, value, m, matrix.device, matrix.shape[0])
     x3 = matrix.float().reshape(1, matrix.shape[0], -1).contiguous()
-    return F.csr_hop(op, x3).reshape((m,) + tuple(matrix.shape[1:]))
+    return _spmm3(op, x3, _coo_values(index, value, op)).reshape((m,) + tuple(matrix.shape[1:]))
 
 
 def spmm_batch_2(index, value, m, matrix):
@@ -251,7 +265,7 @@ def spmm_batch_3(index, value, m, matrix):
     op = _coo_operand(index, value, m, matrix.device, matrix.shape[1])
     sh = matrix.shape
     x3 = matrix.float().reshape(sh[0], sh[1], -1).contiguous()
-    return F.csr_hop(op, x3).reshape((sh[0], m) + tuple(sh[2:]))
+    return _spmm3(op, x3, _coo_values(index, value, op)).reshape((sh[0], m) + tuple(sh[2:]))
 
 
 # ------------------------------------------------------------------------------------ edge-list classes
@@ -261,8 +275,29 @@ class _EdgeBase(torch.nn.Module):
         if edge_weight is not None:
             assert edge_weight.reshape(-1).size(0) == edge_index.size(1)
         key = (_tensor_key(edge_index), _tensor_key(edge_weight), n, str(x.device))
-        return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, edge_weight, n, x.device),
+        w = None if edge_weight is None else edge_weight.detach()
+        return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, w, n, x.device),
                              sources=(edge_index, edge_weight))
+
+    def _values(self, x, edge_index, edge_weight, op):
+        """The operand's values in CSR order as a function of a LEARNABLE edge_weight (None otherwise): lap_e = -deg^-1/2[row] w_e deg^-1/2[col]
+        with the unweighted source degree (gcn.py:408-413), i.e. a constant coefficient per kept edge times its weight -- differentiable index
+        plumbing; the arithmetic of the gradient itself is F.chebyshev_values_grad."""
+        if edge_weight is None or not edge_weight.requires_grad:
+            return None
+        n, dev = x.size(1), x.device
+
+        def links():
+            row, col = edge_index[0].to(dev).long(), edge_index[1].to(dev).long()
+            ids = (row != col).nonzero().flatten()
+            r, c = row[ids], col[ids]
+            order = torch.argsort(r * n + c, stable=True)            # the order GraphOperand.from_coo packs: (row, col), duplicates as given
+            dis = torch.bincount(r, minlength=n).to(torch.float32).pow(-0.5)
+            dis[torch.isinf(dis)] = 0
+            return ids[order], (-(dis[r] * dis[c]))[order]
+        src, coef = self._ops.get(("links", _tensor_key(edge_index), n, str(dev)), links, sources=(edge_index,))
+        assert src.numel() == op.nnz
+        return coef * edge_weight.to(device=dev, dtype=torch.float32).reshape(-1)[src]
 
     def reset_parameters(self):
         size = self.in_channels * self.weight.size(0)
@@ -295,7 +330,8 @@ class ChebConv(_EdgeBase):
                 F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)
 
     def forward(self, x, edge_index, edge_weight=None):
-        return F.cheb_layer(*self._layer_args(x, edge_index, edge_weight))
+        args = self._layer_args(x, edge_index, edge_weight)
+        return F.cheb_layer(*args, values=self._values(x, edge_index, edge_weight, args[0]))
 
 
 class ChebTimeConv(_EdgeBase):
@@ -322,7 +358,8 @@ class ChebTimeConv(_EdgeBase):
                 F.BIAS_NONE if self.bias is None else F.BIAS_CHANNEL, F.MODE_CHEBYSHEV)
 
     def forward(self, x, edge_index, edge_weight=None):
-        return F.cheb_layer(*self._layer_args(x, edge_index, edge_weight))
+        args = self._layer_args(x, edge_index, edge_weight)
+        return F.cheb_layer(*args, values=self._values(x, edge_index, edge_weight, args[0]))
 
 
 # ------------------------------------------------------------------------------------ fused caller pattern
@@ -330,4 +367,7 @@ def cheb_relu_pool(layer, x, *graph_args, pool=4):
     """gcn_pool_4(F.relu(layer(x, ...)))  (pool=4)  /  gcn_pool(F.relu(layer(x, ...)))  (pool=2)  in one fused op:
     additive API for the pattern of examples/pytorch_based/pytorch_hcp_tgcn.py:134-141 and pytorch_mnist_gcn.py.
     `layer` is any of the five modules above; graph_args are ChebConv's (edge_index[, edge_weight])."""
+    if len(graph_args) > 1 and graph_args[1] is not None and graph_args[1].requires_grad:
+        # learnable edge weights: the gradient w.r.t. them belongs to the layer function; relu + pool as their own pass behind it
+        return F.ReluPoolFn.apply(layer(x, *graph_args), pool)
     return F.cheb_relu_pool(*layer._layer_args(x, *graph_args), pool)
