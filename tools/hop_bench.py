@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--drop-core", type=int, default=None, help="remove the entries whose row AND column are among the H vertices of largest degree (what a hub-core kernel would take over)")
     ap.add_argument("--no-wave-rows", action="store_true", help="graph.WAVE_ROWS = False: medium rows as lane-group segments too")
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
+    ap.add_argument("--cold-last", type=int, default=None, help="reorder the entries inside every row: entries whose column is among the RANK most referenced "
+                    "columns first (in column order), the others behind them (in column order) -- a gather instruction then carries lines of one latency class")
     args = ap.parse_args()
     from tools import synth
     from tgcn_amd import _lib, graph, functional as F
@@ -76,6 +78,20 @@ def main():
         plan = op.compact_plan()
         print("compact: %d rows with entries, %d empty" % (plan.n_c, plan.n_empty), flush=True)
         op = plan.rest
+    if args.cold_last is not None:
+        # popularity of a column = stored entries that point at it; stable sort of the entries by (row, is_cold) keeps the column order inside both classes
+        cols = op.edges[: op.nnz, 0].long()
+        pop = torch.bincount(cols, minlength=op.n_cols)
+        rank = torch.empty_like(pop)
+        rank[torch.argsort(pop, descending=True, stable=True)] = torch.arange(op.n_cols, device=dev)
+        cold = (rank[cols] >= args.cold_last)
+        counts = (op.rowptr[1:] - op.rowptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(op.n, device=dev), counts)
+        order = torch.argsort(rows * 2 + cold.long(), stable=True)
+        print("cold-last: %d of %d entries point at a column outside the %d most referenced" % (int(cold.sum()), op.nnz, args.cold_last), flush=True)
+        edges2 = op.edges[: op.nnz][order].contiguous()
+        del cols, pop, rank, cold, rows, order
+        op = graph.GraphOperand._from_packed(op.n, op.rowptr, edges2, op.nnz, n_cols=op.n_cols)
     lanes = _lib.lib().tgcn_hop_lanes_per_row(args.C // args.split, 1)
     scheds = {m: graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, seg_mode=m, n_cols=op.n_cols) for m in sorted(set(int(m) for m in args.seg_modes.split(",")))}
     for m, sm in scheds.items():
