@@ -16,6 +16,9 @@ aggregate.  --shard vertex / hybrid run the vertex-sharded layer (halo / all-gat
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = hop_kernel,
 algorithmic bytes per launch / mean launch duration from hipEvents recorded around every hop launch of the timed
 steps) and `cpu_baseline` (oracle/cheb_ref.c, OpenMP, timed on this box's host cores on a bounded sample).
+`roofline.physical_*`: the same for the bytes a launch physically has to move once (entries, row pointers, and only the rows that exist in
+the hop tensors -- compaction is fewer rows processed, not more bandwidth); `roofline.mean_launch_ms_by_hop`: by hop position.
+N > 1: the vertex-sharded / hybrid extras (`other_shardings`) size themselves to --extras-budget and never decide the exit code.
 """
 import argparse
 import json
