@@ -34,7 +34,7 @@ def _dense_lap(ei, w, n):
 
 
 @pytest.mark.parametrize("n,E,q,f,g,K,H", [(60, 400, 3, 4, 5, 3, 0), (60, 400, 2, 1, 8, 1, 0), (60, 400, 2, 3, 4, 2, 0), (3000, 30000, 2, 16, 8, 5, 0),
-                                           (148, 3000, 2, 1, 6, 4, 5), (3000, 30000, 1, 2, 4, 3, 6)])
+                                           (148, 3000, 2, 1, 6, 4, 5), (3000, 30000, 1, 2, 4, 3, 6), (300, 2400, 2, 3, 5, 10, 0)])
 def test_edge_weight_gradient_of_the_chebyshev_layers(n, E, q, f, g, K, H, gpu_device):
     import tgcn_amd
     rng = np.random.default_rng(n + K + H)

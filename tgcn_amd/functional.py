@@ -343,9 +343,13 @@ def compact_plan_for(op, mode, K, q, n, C_row, N=None):
     for the isolated rest)."""
     if not COMPACT or not (2 <= K <= 32) or op.n != op.n_cols:
         return None
-    if choose_layout(q, n, C_row) == 1 and not (COMPACT_LAYOUT1 and N is not None and K * C_row <= 16 and N % 4 == 0 and N <= 1024 and n * q >= 1 << 16):
+    lay1 = choose_layout(q, n, C_row) == 1
+    if lay1 and not (COMPACT_LAYOUT1 and N is not None and K * C_row <= 16 and N % 4 == 0 and N <= 1024):
         return None       # the vertex-major form needs the vector-ALU projection (row map + interleave: a few scalars per row)
-    return op.compact_plan("rows" if mode == MODE_POWER else "closed")
+    plan = op.compact_plan("rows" if mode == MODE_POWER else "closed")
+    if plan is not None and lay1 and (plan.n_c * q < 4096 or 0 < plan.n_empty * q < 4096):
+        return None       # ... which takes problems of at least 4096 rows: both row classes must qualify (project_choose in the library)
+    return plan
 
 
 def _compact_buffer(plan, q, C_row, device):
