@@ -254,7 +254,7 @@ class _CpuLayer:
         return torch.from_numpy(sum(Xt[k] @ self.W[k] for k in range(self.K)).astype(np.float32))
 
 
-def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, rehearsal=False):
+def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, rehearsal=False, exchange="auto"):
     """The vertex-sharded layer of SURVEY.md 8(e) on the same workload: every rank holds the seeded graph, owns an nnz-balanced
     row range (inside its group of `vertex_shards` ranks for mode "hybrid"; the groups split the q_total time steps, no
     communication between them) and its slice of x / bias.  -> (callable(overlap), VertexShardedCheb, groups, time steps of this group)"""
@@ -269,7 +269,7 @@ def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, r
     q = sl.stop - sl.start
     row, col, val = op.coo()
     hooks = dict(make_operand=_CpuOperand, hop_fn=_cpu_hop, project_fn=_cpu_project, pack_fn=_cpu_pack) if rehearsal else {}
-    sh = VertexShardedCheb(op.n, row, col, val, group=group, device=device, exchange="auto", **hooks)
+    sh = VertexShardedCheb(op.n, row, col, val, group=group, device=device, exchange=exchange, **hooks)
     del row, col, val
     K = spec["K"]
     torch.manual_seed(1)
@@ -284,18 +284,51 @@ def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, r
     return (lambda overlap=True, qs=None: sh.forward(x_local if qs is None else x_local[:qs], Wf, bias_local, 2, 0, overlap=overlap)), sh, ngroups, q
 
 
+class Progress:
+    """What the extras are doing right now, for the watchdog's record: the phase that is running, whether the host sits in a collective or in
+    a device synchronise (and since when), and the seconds every finished phase took.  Plain attribute writes from the main thread, read once by
+    the watchdog thread."""
+
+    def __init__(self):
+        self.t0 = time.perf_counter()
+        self.phase, self.phase_t0 = None, self.t0
+        self.in_sync_since = self.in_collective_since = None
+        self.elapsed = []                      # [(phase, seconds)] in order
+
+    def enter(self, phase):
+        now = time.perf_counter()
+        if self.phase is not None:
+            self.elapsed.append((self.phase, round(now - self.phase_t0, 3)))
+        self.phase, self.phase_t0 = phase, now
+
+    def record(self, budget):
+        now = time.perf_counter()
+        sync_s = None if self.in_sync_since is None else now - self.in_sync_since
+        coll_s = None if self.in_collective_since is None else now - self.in_collective_since
+        # a run that is merely slow keeps finishing phases: every (sharding, form) pair sizes itself to a fraction of the budget, so ONE device
+        # synchronise (or collective) that has lasted more than half of the whole budget is a stall, not a slow transport
+        # (at least 20 s: a budget of a few seconds, as tests use, says nothing about a stall)
+        stalled = max(sync_s or 0.0, coll_s or 0.0) > max(0.5 * budget, 20.0)
+        return dict(phase=self.phase, phase_elapsed_s=round(now - self.phase_t0, 3), in_device_sync=sync_s is not None,
+                    device_sync_elapsed_s=None if sync_s is None else round(sync_s, 3), in_collective=coll_s is not None,
+                    collective_elapsed_s=None if coll_s is None else round(coll_s, 3), total_elapsed_s=round(now - self.t0, 3),
+                    finished_phases_s=list(self.elapsed), stalled=stalled)
+
+
 def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, progress=None, out=None):
     """Vertex-sharded and hybrid runs of the same workload (2 timed forwards each), each in two forms: "plain" (one blocking
     exchange per hop, then the hop: the form with the fewest ways to go wrong on a first contact with RCCL) and "overlapped"
     (in-place receives, interior rows and other time steps under the exchange).  They must never cost the headline: every failure
     becomes an entry with an `error`, entries are appended to `out` as they finish, and every (sharding, form) pair SIZES ITSELF to
-    its share of --extras-budget: one time step is run first (untimed: communicators, buffers), a second one is timed on every
+    its share of --extras-budget: the remaining budget is checked BEFORE anything runs (an entry whose share is already spent is skipped
+    with an explicit error), one time step is run first (untimed: communicators, buffers), a second one is timed on every
     rank (max over ranks), and the measured forwards then take as many of the group's time steps as fit the share
     (`time_steps_used`; time steps are independent columns, so the rate per time step is the same quantity).  Should a run still
-    overrun the whole budget, the caller's watchdog prints the headline with the entries finished so far and ends every rank.
-    Every entry carries what each rank exchanges per hop (rows, bytes per channel and peer) and its per-phase times, so a slow or
-    wrong run can be diagnosed from the one line."""
+    overrun the whole budget, the caller's watchdog prints the headline with the entries finished so far, the phase record of `progress`,
+    and ends every rank.  Every entry carries what each rank exchanges per hop (rows, bytes per channel and peer) and its per-phase times,
+    so a slow or wrong run can be diagnosed from the one line."""
     out = [] if out is None else out
+    progress = Progress() if progress is None else progress
     K, H = spec["K"], spec["H"]
     rehearsal = getattr(args, "rehearsal_cpu", False)
     modes = [("vertex", world)] + ([("hybrid", 2)] if world >= 4 and world % 2 == 0 else [])
@@ -305,14 +338,21 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
 
     def agree(v, red):
         t = torch.tensor([v], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        progress.in_collective_since = time.perf_counter()
         dist.all_reduce(t, op=red)
-        return float(t.item())
+        v = float(t.item())
+        progress.in_collective_since = None
+        return v
+
+    def synced():
+        progress.in_sync_since = time.perf_counter()
+        sync_all()
+        progress.in_sync_since = None
 
     for mi, (mode, vs) in enumerate(modes):
         try:
-            if progress is not None:
-                progress["mode"] = "%s: building shards" % mode
-            fwd, sh, ngroups, qg = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs, rehearsal)
+            progress.enter("%s: building shards" % mode)
+            fwd, sh, ngroups, qg = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs, rehearsal, args.extras_exchange)
         except Exception as e:      # noqa: BLE001 -- reported, never fatal
             import traceback
             traceback.print_exc()
@@ -321,17 +361,23 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
             continue
         for fi, (form, overlap) in enumerate((("plain", False), ("overlapped", True))):
             entry = dict(shard=mode, vertex_shards=vs, form=form)
-            if progress is not None:
-                progress["mode"] = "%s / %s" % (mode, form)
             try:
                 steps = 2
                 sh.collect_stats = False
+                progress.enter("%s / %s: budget check" % (mode, form))
+                left = agree(usable - (time.perf_counter() - t_start), dist.ReduceOp.MIN)
+                if left <= 0:      # shard construction (or an earlier entry) already ate the budget: do not even start the set-up forward
+                    entry["error"] = "skipped: the usable extras budget (%.0f s of --extras-budget %.0f s) was spent before this entry's set-up forward" % (usable, args.extras_budget)
+                    out.append(entry)
+                    continue
                 with torch.no_grad():
+                    progress.enter("%s / %s: set-up forward (1 time step, untimed)" % (mode, form))
                     fwd(overlap, 1)                         # set-up: communicators, exchange buffers, allocator
-                    sync_all()
+                    synced()
+                    progress.enter("%s / %s: one timed time step" % (mode, form))
                     t0 = time.perf_counter()
                     fwd(overlap, 1)
-                    sync_all()
+                    synced()
                     t1 = agree(time.perf_counter() - t0, dist.ReduceOp.MAX)          # one time step, slowest rank
                     # this entry's share of what is left of the usable budget, spread over its steps + 1 phase-log forwards;
                     # every rank computes the same number from the same all-reduced inputs
@@ -345,20 +391,25 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
                     else:
                         if share < (steps + 1.5) * t1:
                             steps = 1
+                        progress.enter("%s / %s: %d measured forward(s) of %d time step(s)" % (mode, form, steps, qs))
                         t0 = time.perf_counter()
                         for _ in range(steps):
                             fwd(overlap, qs)
-                        sync_all()
+                        synced()
                         dt = time.perf_counter() - t0
+                        progress.enter("%s / %s: phase-log forward" % (mode, form))
                         sh.collect_stats = True                # one more forward with the phase log (device events add their own syncs)
                         fwd(overlap, qs)
-                        sync_all()
+                        synced()
                         sh.collect_stats = False
                         phases = sh.stats
                         dt = agree(dt, dist.ReduceOp.MAX)
+                progress.enter("%s / %s: gathering the per-rank records" % (mode, form))
                 mine = dict(sh.describe(), phases_ms=phases)
                 per_rank = [None] * world
+                progress.in_collective_since = time.perf_counter()
                 dist.all_gather_object(per_rank, mine)
+                progress.in_collective_since = None
                 C_in = spec["H"] * spec["f"]
                 # the groups of a hybrid grid run side by side: together they cover ngroups * qs time steps per forward
                 entry.update(value=round(op.nnz * (K - 1) * (qs * ngroups) * H * steps / dt / 1e9, 3), unit="G edge·timesteps/s", ms_per_step=round(dt / steps * 1e3, 3),
@@ -370,11 +421,39 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
                 traceback.print_exc()
                 sys.stderr.flush()
                 entry["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+            progress.in_sync_since = progress.in_collective_since = None
             out.append(entry)
         del fwd, sh
         if device.type == "cuda":
             torch.cuda.empty_cache()
+    progress.enter("done")
     return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: this process becomes the parent of
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` -- a CHILD process, never an exec -- and
+    returns its exit code; the ranks inherit stdout / stderr, so rank 0's ONE JSON line is this command's output.  Nothing here touches
+    the GPU: torch.cuda.device_count() only counts devices (it does not initialise the runtime), and a rank count the node cannot hold is
+    refused before anything starts instead of being run on fewer GPUs."""
+    import socket
+    import subprocess
+    if not args.rehearsal_cpu:
+        have = torch.cuda.device_count()
+        if args.gpus > have:
+            print("bench.py: --gpus %d but this node has %d GPU(s); refusing to run the scaling bench on fewer devices" % (args.gpus, have), file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool: RCCL's cross-process handles need it
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
 def main():
@@ -398,9 +477,14 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="developer: key=value for tgcn_set_tuning (repeatable)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1, time sharding: skip the vertex-sharded / hybrid runs reported in `other_shardings`")
     ap.add_argument("--rehearsal-cpu", action="store_true", help="tests only: run the N > 1 control flow on the CPU with the gloo backend and scipy stand-ins for the HIP calls; nothing measured in this mode is a result")
+    ap.add_argument("--force-extras", action="store_true", help="run the vertex-sharded extras also at world 1 (one rank under a launcher: the collectives of the N > 1 path meet RCCL)")
+    ap.add_argument("--extras-exchange", default="auto", choices=["auto", "halo", "allgather"], help="exchange form of the vertex-sharded runs (auto: all-gather when the halo is most of the graph)")
     ap.add_argument("--extras-budget", type=float, default=150.0, help="seconds after which the extra runs are abandoned and the headline line is printed without them")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # started by torch.distributed.run (the driver's N > 1 command, or self_launch)
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args))          # parent: no GPU call has been made in this process, and none will be
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -413,13 +497,16 @@ def main():
         local = local % torch.cuda.device_count()      # rehearsals may put several ranks on one card
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
-    if world > 1:
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch with torch.distributed.run --nproc-per-node %d (or plain `python bench.py --gpus %d`, "
+                         "which starts that launcher itself)" % (args.gpus, world, args.gpus, args.gpus))
+    dist = None
+    if launched:          # also at world 1: `torch.distributed.run --nproc-per-node 1 bench.py` runs the collectives of the N > 1 path on one rank
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from tgcn_amd import _lib, functional as _F
     if args.no_small_path:
@@ -440,10 +527,10 @@ def main():
         mine = shard_time_steps(spec["q"], rank, world)
         spec["q"] = mine.stop - mine.start
     K, q, H = spec["K"], spec["q"], spec["H"]
-    vertex_mode = world > 1 and args.shard in ("vertex", "hybrid")
+    vertex_mode = dist is not None and args.shard in ("vertex", "hybrid")       # world 1 under a launcher: the same code on one rank (first contact with RCCL)
     ngroups = 1
     if vertex_mode:
-        fwd, sh, ngroups, q = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards, rehearsal)
+        fwd, sh, ngroups, q = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards, rehearsal, args.extras_exchange)
         spec["q"] = q
 
         class _Sharded:
@@ -461,7 +548,7 @@ def main():
     def sync_all():
         if device.type == "cuda":
             torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             if device.type == "cuda":
                 torch.cuda.synchronize()
@@ -484,7 +571,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         prof = [] if rehearsal else _lib.profile_stop(65536)
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -604,7 +691,7 @@ def main():
         line = dict(metric=baseline_metric(), value=round(value, 3), unit="G edge\u00b7timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="strong" if (vertex_mode or strong_time or world == 1) else "weak", vs_baseline=None,
                     dtype="f32", data="rehearsal on the CPU with scipy stand-ins: control flow only, NOT a measurement" if rehearsal else "synthetic",
-                    config=dict(workload=spec["desc"], K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
+                    config=dict(workload=spec["desc"], dist_backend=(args.backend if dist is not None else None), K=K, time_steps_per_gpu=q * H, C_in=spec["f"], C_out=spec["g"],
                                 sharding=(("%d group(s) x %d vertex shards, %s exchange per hop inside a group" % (ngroups, sh.world, sh.exchange)) if ngroups > 1 else ("vertex rows across ranks, %s exchange per hop" % sh.exchange)) if vertex_mode else (("the %d time steps of the workload split over %d ranks (%d on rank 0), CSR replicated, no collective" % (q_total, world, q) if strong_time else "%d time steps per rank, CSR replicated, no collective" % q) if world > 1 else "single GPU"),
                                 nnz=op.nnz, n=op.n,
                                 arithmetic="f32 (bf16x3 projection: fp32 operands split into three bf16 terms on the matrix pipe)" if x3_proj else "f32",
@@ -614,24 +701,29 @@ def main():
                     roofline=roofline, cpu_baseline=cpu)
     # ---- N > 1: the mandated vertex-sharded scheme (and the hybrid grid) on the same workload, reported next to the headline.
     # A watchdog on every rank prints the headline without them and ends the process if they overrun their budget.
-    if world > 1 and args.shard == "time" and not args.no_extras and spec["cls"] in ("TGCNCheb", "TGCNCheb_H"):
+    if dist is not None and (world > 1 or args.force_extras) and args.shard == "time" and not args.no_extras and spec["cls"] in ("TGCNCheb", "TGCNCheb_H"):
         import threading
         printed = threading.Lock()         # exactly one JSON line, whoever gets there first
-        progress = dict(mode=None)
+        progress = Progress()
         extras = []                        # entries finished so far: the watchdog prints them with the headline
 
         def bail():
-            # a stalled exchange (or a GPU hang) in the extras: the headline WAS measured, so print it -- marked `extras_abandoned`,
-            # with the entries that finished -- and end every rank with code 0: the extras never decide the exit code of the
-            # scaling run (plain exit, never a re-exec; a rank stuck in a collective cannot be joined, hence os._exit)
+            # the extras overran --extras-budget.  The headline WAS measured, so print it -- marked `extras_abandoned`, with the entries that
+            # finished and the machine-readable record of where the extras stood (`extras_abandon`: phase, whether the host sat in a device
+            # synchronise or a collective and for how long, seconds per finished phase).  Exit code: 0 when the run was merely slow (phases kept
+            # finishing); 3 when ONE device synchronise / collective had been pending for more than half of the whole budget -- a stalled
+            # exchange or a GPU hang must not read as success on the 8-GPU box.  Plain exit, never a re-exec; a rank stuck in a collective
+            # cannot be joined, hence os._exit.
             if not printed.acquire(blocking=False):
                 return
+            rec = progress.record(args.extras_budget)
             if rank == 0:
                 line["extras_abandoned"] = True
-                line["other_shardings"] = list(extras) + [dict(error="abandoned after %.0f s (--extras-budget)" % args.extras_budget, last_started=progress["mode"])]
+                line["extras_abandon"] = rec
+                line["other_shardings"] = list(extras) + [dict(error="abandoned after %.0f s (--extras-budget)" % args.extras_budget, last_started=rec["phase"])]
                 print(json.dumps(line), flush=True)
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3 if rec["stalled"] else 0)
         dog = threading.Timer(args.extras_budget, bail)
         dog.daemon = True
         dog.start()
@@ -644,7 +736,7 @@ def main():
             print(json.dumps(line), flush=True)
     elif rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -72,3 +72,49 @@ def test_extras_size_themselves_to_a_small_budget():
     for e in extras:
         assert "error" not in e, e
         assert 1 <= e["time_steps_used"] <= e["time_steps_per_group"] == 16 and e["value"] > 0 and e["one_time_step_ms"] > 0
+
+
+def _bare(extra, env_extra=None, timeout=300):
+    """`python bench.py ...` with NO launcher and no rendezvous variables in the environment"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` used to run ONE rank and print n_gpus 1 when WORLD_SIZE was unset; the parent now
+    starts torch.distributed.run as a child and relays the one line and the exit code."""
+    r = _bare(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearsal-cpu", "--vertices", "3000", "--entries", "40000", "--no-extras"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["config"]["dist_backend"] == "gloo"
+    assert "split over 2 ranks" in lines[0]["config"]["sharding"]
+    assert "starting 2 ranks" in r.stderr
+
+
+def test_more_ranks_than_gpus_is_refused_not_degraded():
+    """no GPU in the CPU suite's container (or fewer than 64 anywhere): the scaling command must fail, not run on fewer devices"""
+    r = _bare(["--gpus", "64", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 2 and "refusing" in r.stderr and not _json_lines(r.stdout)
+
+
+def test_rank_count_mismatch_with_the_launcher_is_an_error():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal-cpu", "--vertices", "3000", "--entries", "40000"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not _json_lines(r.stdout)
+
+
+def test_one_rank_under_the_launcher_runs_the_collectives_and_the_extras():
+    """world 1 with a process group: the all-reduce of the timing and (--force-extras) the all-gather form of the vertex-sharded layer run
+    on one rank -- the CPU twin of the GPU suite's first contact with RCCL (tests/test_dist_gpu.py)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--rehearsal-cpu",
+           "--vertices", "3000", "--entries", "40000", "--force-extras", "--extras-exchange", "allgather"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_lines(r.stdout)[0]
+    assert line["n_gpus"] == 1 and line["config"]["dist_backend"] == "gloo"
+    assert [(e["shard"], e["form"], e.get("exchange")) for e in line["other_shardings"]] == [("vertex", "plain", "allgather"), ("vertex", "overlapped", "allgather")]

@@ -65,3 +65,84 @@ def test_vertex_sharded_hip_two_ranks_one_gpu(exchange, banded, gpu_device):
     assert len(ret) == world and sum(ret[r][2] for r in range(world)) == 3000
     for r in range(world):
         assert ret[r][0] <= 1e-5 and ret[r][1] == exchange, ret[r]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# First contact with RCCL.  A one-GPU box cannot hold two NCCL ranks (RCCL refuses two ranks on one device), so
+# the N > 1 code meets the real backend at world size 1: init_process_group("nccl", device_id=...), all_reduce on a device tensor,
+# all_gather_into_tensor(async_op=True) + work.wait() with RCCL's stream ordering (the collective runs on RCCL's own stream; wait() only
+# makes torch's current stream wait for it -- gloo blocks the host instead), batch_isend_irecv-free halo form, and bench.py's N > 1 path.
+def _nccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from tgcn_amd.dist import VertexShardedCheb
+        t = torch.tensor([3.5], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 3.5
+        rng = np.random.default_rng(5)
+        n, q, C, N, K = 5000, 5, 64, 32, 5            # q = 5 with depth 2: full and ragged pipeline groups
+        row, col = rng.integers(0, n, 10 * n), rng.integers(0, n, 10 * n)
+        row = np.concatenate([row, np.full(700, 11)])               # one long row: segment + fix-up path inside the sharded hop
+        col = np.concatenate([col, rng.integers(0, n, 700)])
+        val = (rng.standard_normal(row.shape[0]) / 3).astype(np.float32)
+        x = rng.standard_normal((q, n, C)).astype(np.float32)
+        W = (rng.standard_normal((K, C, N)) / 4).astype(np.float32)
+        bias = rng.standard_normal((n, N)).astype(np.float32)
+        L = O.coo_to_csr(row, col, val, n)
+        res = {}
+        for exchange in ("allgather", "halo"):
+            for mode in (0, 1):
+                sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), device=dev, exchange=exchange)
+                assert sh.exchange == exchange and sh.owned == n
+                args = (torch.as_tensor(x).to(dev), torch.as_tensor(W).to(dev), torch.as_tensor(bias).to(dev), 2, mode)
+                out = sh.forward(*args)                       # overlapped: async all-gather / p2p batch, wait() on the compute stream
+                out3 = sh.forward(*args, depth=3)
+                plain = sh.forward(*args, overlap=False)
+                torch.cuda.synchronize()
+                assert torch.equal(out, plain) and torch.equal(out3, plain), "overlapped and plain forms differ under RCCL"
+                if mode == 1:
+                    stack = O.stack_chebyshev(L, x, K)
+                else:           # mode 0 takes the weight in the monomial basis: terms L^k x
+                    stack = np.empty((K,) + x.shape, np.float32)
+                    stack[0] = x
+                    for k in range(1, K):
+                        stack[k] = O._apply(L, stack[k - 1])
+                ref = np.einsum("kqnc,kcg->qng", stack.astype(np.float64), W.astype(np.float64)) + bias
+                res[(exchange, mode)] = float(np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max())
+        ret["err"] = res
+        ret["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_first_contact_with_rccl_world_1(gpu_device):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret["backend"] == "nccl"
+    assert len(ret["err"]) == 4 and all(e <= 1e-5 for e in ret["err"].values()), dict(ret["err"])
+
+
+def test_bench_n_gt_1_path_on_rccl_one_rank(gpu_device):
+    """bench.py under the driver's own launcher with the nccl backend on one rank: rendezvous with device_id, barrier, the all-reduce of the
+    timing, and the vertex-sharded extras (all-gather form, plain + overlapped) -- the code an 8-GPU lease would run, minus the peers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--backend", "nccl", "--steps", "2", "--warmup", "1", "--no-cpu", "--vertices", "200000",
+           "--entries", "3000000", "--force-extras", "--extras-exchange", "allgather", "--extras-budget", "120"]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["config"]["dist_backend"] == "nccl" and line["value"] > 0 and "extras_abandoned" not in line
+    forms = [(e["shard"], e["form"], e.get("exchange"), "error" in e) for e in line["other_shardings"]]
+    assert forms == [("vertex", "plain", "allgather", False), ("vertex", "overlapped", "allgather", False)], line["other_shardings"]
+    for e in line["other_shardings"]:
+        assert e["value"] > 0 and e["ranks"][0]["owned_rows"] == 200000 and e["ranks"][0]["phases_ms"]

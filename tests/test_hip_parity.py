@@ -274,9 +274,10 @@ def test_hop_linearity_large(gpu_device):
                                             (333, 7, 5, 2, 1), (1200, 12, 15, 4, 4), (64 * 9, 3, 100, 2, 9), (500, 36, 40, 33, 1),
                                             (5000, 64, 64, 5, 1), (4100, 200, 32, 3, 1), (70, 130, 17, 2, 1), (20000, 64, 64, 5, 1), (9000, 100, 160, 1, 1),
                                             (6000, 1, 64, 5, 16), (4099, 4, 256, 4, 1), (5000, 2, 1024, 8, 1), (4500, 1, 32, 33, 1)])
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 6])
 def test_project_vs_numpy(M, Kc, N, T, inter, variant, gpu_device):
-    """variant 0: shipped choice (bf16x3 on large problems, exact fp32 otherwise); 1: exact-fp32 streaming-W kernel
+    """variant 6: the barrier-free streaming bf16x3 kernel wherever the shape has it (rows of 32 / 64 floats, <= 64 columns; the shipped
+    choice takes it from 32768 rows), the shipped choice elsewhere.  variant 0: shipped choice (bf16x3 on large problems, exact fp32 otherwise); 1: exact-fp32 streaming-W kernel
     everywhere; 3: bf16x3 everywhere (fp32-accurate products on the bf16 matrix pipe); 4: exact fp32, W-resident
     kernel where the weight fits in LDS; 5: the vector-ALU kernel for narrow contractions (sum of Kc <= 16) wherever it
     applies (variant 0 picks it from M >= 4096)."""
@@ -865,7 +866,7 @@ def test_hop_batch_beyond_the_grid_limit(gpu_device):
     assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) <= TOL
 
 
-@pytest.mark.parametrize("variant", [3, 0])
+@pytest.mark.parametrize("variant", [3, 0, 6])
 def test_bf16x3_projection_mixed_magnitudes(variant, gpu_device):
     """The three-way bf16 split of the projection (project.h: a = a1 + a2 + a3, six of the nine cross products kept) against
     fp64 on adversarial ranges: per-row scales 1e-6 ... 1e6, per-term scales spread over 12 decades, terms that cancel, and

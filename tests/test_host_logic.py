@@ -182,6 +182,11 @@ def test_hot_kernels_keep_their_register_budget():
     assert hop["vgpr"] <= 72 and hop["spill"] == 0, hop          # 7 waves per SIMD
     assert find("hop_kernelILi4ELi4ELi4ELi1ELi0")["vgpr"] <= 64  # cfg5n's hop: 8 waves per SIMD
     assert find("project_narrow_kernel")["vgpr"] <= 128
+    # round 5: the streaming bf16x3 projection runs ONE 1024-thread workgroup per CU = 4 waves per SIMD: 128 VGPRs, nothing spilled
+    for nt in (1, 2, 4):
+        for kt in (1, 2):
+            st = find("project_x3_stream_kernelILi%dELi%dE" % (nt, kt))
+            assert st["vgpr"] <= 128 and st["spill"] == 0, (nt, kt, st)
 
 
 def test_geometry_queries():

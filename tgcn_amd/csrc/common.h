@@ -109,3 +109,23 @@ SideStream* side_stream() {
 
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Device of a caller's data pointer against the calling thread's current device.  The stream a caller hands in belongs to its current
+// device, and every launch goes there: a module moved to cuda:1 and called while cuda:0 is current would run on the wrong GPU (the
+// reference's torch ops follow the TENSOR's device, tgcn/nn/gcn.py:141,147; SURVEY.md 8b "honour ... the device of the pointers").
+// One hipPointerGetAttributes per layer / hop call; skipped while the stream is being captured into a hipGraph (the capture was started
+// on that device by construction).
+inline int check_pointer_device(const void* p, hipStream_t st, const char* who) {
+  if (!p) return TGCN_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return TGCN_OK; }
+  if (cs != hipStreamCaptureStatusNone) return TGCN_OK;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return TGCN_OK;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return TGCN_OK; }    // not a pointer the runtime knows: nothing to say
+  if (at.type == hipMemoryTypeDevice && at.device != cur)
+    TGCN_FAIL(TGCN_ERR_INVALID, "%s: the data is on device %d but the calling thread's current device is %d -- make the tensor's device current "
+                                "(hipSetDevice / torch.cuda.device) and pass that device's stream", who, at.device, cur);
+  return TGCN_OK;
+}

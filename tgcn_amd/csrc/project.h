@@ -942,6 +942,181 @@ __global__ __launch_bounds__(512) void project_x3v2_kernel(const ProjParams p, c
   else x3v2_body<NT, 1>(p, lds_raw, (int64_t)main_blocks * 256 + (int64_t)(bx - main_blocks) * 128, n0);
 }
 
+// ---- bf16x3, STREAMING form (round 5): rows of 32 / 64 floats, <= 64 output columns, the whole weight resident -- the shape of the
+// row-mapped projections of the compacted forward (cfg5: 4.73 M compact rows x 5 terms, 5.27 M empty rows x 1 term, per time step).
+// project_x3_kernel runs those at 4.0 / 3.3 TB/s: per 32-k tile a workgroup loads, waits, barriers, splits A and W into LDS, barriers and
+// multiplies, so loads are in flight for a small part of each tile's time (46 line requests per CU on average, profiles/r04_projection_limiter.json),
+// and the matrix, vector and LDS pipes (each ~30 % busy) take turns instead of overlapping.  Here nothing in the loop is shared between waves:
+//   * the three bf16 planes of the WHOLE weight are split once per workgroup into LDS, already in MFMA fragment order (one conflict-free
+//     ds_read_b128 per fragment), and stay there: no W traffic, no split and no barrier in the loop;
+//   * the product is evaluated transposed, out^T = W^T x^T: the weight is the A operand (rows = output columns), a wave's 16 rows of x are the
+//     B operand -- B[k = 8 (l >> 4) + j][col = l & 15] is 8 floats of row (l & 15), loaded global -> registers -> split -> MFMA with no LDS
+//     round trip -- and the result D[row = 4 (l >> 4) + i][col = l & 15] leaves lane l with FOUR CONSECUTIVE output columns of its row:
+//     bias loads and stores are 16-byte pieces straight from the accumulators, no epilogue scratch;
+//   * the k slots of an MFMA are a permutation of the row's floats (slot (g, j) of k tile kt = float 32 kt + 16 (j >> 2) + 4 g + (j & 3),
+//     the weight fragments are staged with the same map), so that the four lanes of a row read 64 contiguous bytes per load instruction;
+//   * a wave walks its own 16-row tiles (persistent grid, one 1024-thread workgroup per CU), the samples of the pass and the terms in an
+//     inner loop with the NEXT unit's loads issued before the current unit's 48 MFMAs, and a per-vertex bias row is read once per tile for
+//     all samples of the pass (registers).
+// Same arithmetic as project_x3_kernel (three-way split, six products, smallest first, fp32 accumulate over terms and k tiles in order);
+// the order of the 32 products inside one MFMA differs (slot permutation), so results agree to fp32 rounding, not bit for bit.
+template <int NT, int KTILES>
+__global__ __launch_bounds__(1024) void project_x3_stream_kernel(const ProjParams p, const int64_t ntiles) {
+  extern __shared__ __align__(16) unsigned char stream_smem[];
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  bf16x8* Wf = reinterpret_cast<bf16x8*>(stream_smem);        // [term][kt][nt][plane][lane]: 16 bytes per lane
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  {
+    const int nfrag = p.nterms * KTILES * NT * 64;
+    for (int f = tid; f < nfrag; f += 1024) {
+      const int fl = f & 63, blk = f >> 6;                      // blk = (term * KTILES + kt) * NT + nt
+      const int fnt = blk % NT, fkt = (blk / NT) % KTILES, ft = blk / (NT * KTILES);
+      const int n = fnt * 16 + (fl & 15), fg = fl >> 4;
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = fkt * 32 + 16 * (j >> 2) + 4 * fg + (j & 3);
+        w[j] = (n < p.N) ? p.W[((int64_t)ft * p.Kc + k) * p.N + n] : 0.f;
+      }
+      unsigned pl[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(w[2 * j], w[2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) Wf[(blk * 3 + q) * 64 + fl] = __builtin_bit_cast(bf16x8, u32x4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+    }
+  }
+  __syncthreads();
+  const int64_t nwaves = (int64_t)gridDim.x * 16;
+  const bool map_out = p.rowmap && !(p.mapped & kProjMapTermsOnly);
+  const int units = p.nbatch * p.nterms;                        // (sample, term) units of one tile, sample-major
+
+  // ---- per-tile row state: this lane's row in the tile order (clamped) and through the row map; the map entry of the NEXT tile is
+  // loaded a whole tile ahead so that no unit's loads wait for it
+  int64_t tile = (int64_t)blockIdx.x * 16 + wave;
+  int64_t mrow = 0, rrow = 0, rrow_next = 0;
+  bool row_ok = false;
+  auto tile_rows = [&](int64_t t, int64_t& m_c) { const int64_t m = t * 16 + r16; m_c = m < p.M ? m : p.M - 1; return m < p.M; };
+  auto fetch_map = [&](int64_t t) -> int64_t {
+    if (t >= ntiles) return 0;
+    int64_t m_c; (void)tile_rows(t, m_c);
+    return p.rowmap ? (int64_t)p.rowmap[m_c] : m_c;
+  };
+  float xa[KTILES * 8], xb[KTILES * 8];
+  // unit u of the tile whose rows are (m_c, r_c): term u % nterms of sample u / nterms
+  auto load_unit = [&](int u, int64_t m_c, int64_t r_c, float (&dst)[KTILES * 8]) {
+    const int b = u / p.nterms, t = u - b * p.nterms;            // wave-uniform
+    const int64_t arow = ((p.mapped >> t) & 1u) && p.rowmap ? r_c : m_c;
+    const float* __restrict__ src = p.a[t] + (int64_t)b * p.a_bs[t] + arow * p.lda[t] + 4 * g;
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 v = *reinterpret_cast<const float4*>(src + kt * 32 + h * 16);
+        dst[kt * 8 + h * 4 + 0] = v.x; dst[kt * 8 + h * 4 + 1] = v.y; dst[kt * 8 + h * 4 + 2] = v.z; dst[kt * 8 + h * 4 + 3] = v.w;
+      }
+  };
+  f32x4 acc[NT];
+  float4 bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_bias = [&](int64_t orow) {
+    if (!p.bias_kind) return;
+    const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
+    const float* __restrict__ brow = p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + 4 * g;
+      bv[nt] = (col < p.bias_cols && col < p.N) ? *reinterpret_cast<const float4*>(brow + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // the 48 (KTILES = 2) MFMAs of one unit: per k tile split the lane's 8 floats into the three planes, then for pairs of column tiles
+  // (two independent accumulator chains) the six products, smallest terms first
+  auto compute_unit = [&](int u, const float (&src)[KTILES * 8], int64_t orow, bool ok) {
+    const int b = u / p.nterms, t = u - b * p.nterms;
+    if (t == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt) {
+      unsigned pl[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(src[kt * 8 + 2 * j], src[kt * 8 + 2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
+      bf16x8 xs[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) xs[q] = __builtin_bit_cast(bf16x8, u32x4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+      const bf16x8* wbase = Wf + ((t * KTILES + kt) * NT) * 3 * 64 + lane;
+      constexpr int PAIR = NT >= 2 ? 2 : 1;
+#pragma unroll
+      for (int n0 = 0; n0 < NT; n0 += PAIR) {
+        bf16x8 w[PAIR][3];
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) w[i][q] = wbase[((n0 + i) * 3 + q) * 64];
+        f32x4 c[PAIR];
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) c[i] = acc[n0 + i];
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][0], xs[2], c[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][1], xs[1], c[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][2], xs[0], c[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][0], xs[1], c[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][1], xs[0], c[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][0], xs[0], c[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PAIR; ++i) acc[n0 + i] = c[i];
+      }
+    }
+    if (t == p.nterms - 1 && ok) {                            // last term of the sample: bias and store, 16 bytes per column tile
+      float* __restrict__ o = p.out + (int64_t)b * p.out_bs + orow * p.ldo + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt * 16 + 4 * g >= p.N) continue;
+        f32x4 v = acc[nt];
+        v[0] += bv[nt].x; v[1] += bv[nt].y; v[2] += bv[nt].z; v[3] += bv[nt].w;
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o + nt * 16));        // written once, read by a later kernel
+      }
+    }
+  };
+
+  if (tile < ntiles) {
+    row_ok = tile_rows(tile, mrow);
+    rrow = fetch_map(tile);
+    rrow_next = fetch_map(tile + nwaves);
+    load_unit(0, mrow, rrow, xa);
+  }
+  while (tile < ntiles) {
+    const int64_t orow = map_out ? rrow : mrow;
+    load_bias(orow);
+    const int64_t tile_n = tile + nwaves;
+    int64_t mrow_n = 0;
+    const bool ok_n = tile_n < ntiles ? tile_rows(tile_n, mrow_n) : false;
+    // units of this tile two at a time (statically named register buffers); the unit after the tile's last one is unit 0 of the next tile
+    for (int u = 0; u < units; u += 2) {
+      if (u + 1 < units) load_unit(u + 1, mrow, rrow, xb);
+      else if (tile_n < ntiles) load_unit(0, mrow_n, rrow_next, xb);
+      compute_unit(u, xa, orow, row_ok);
+      if (u + 1 >= units) {                                      // odd unit count: the prefetched unit belongs to the next tile -> move it to xa
+#pragma unroll
+        for (int i = 0; i < KTILES * 8; ++i) xa[i] = xb[i];
+        break;
+      }
+      if (u + 2 < units) load_unit(u + 2, mrow, rrow, xa);
+      else if (tile_n < ntiles) load_unit(0, mrow_n, rrow_next, xa);
+      compute_unit(u + 1, xb, orow, row_ok);
+    }
+    tile = tile_n; mrow = mrow_n; row_ok = ok_n; rrow = rrow_next;
+    rrow_next = fetch_map(tile + nwaves);
+  }
+}
+
 // W-resident variant for the common case where the whole folded weight fits in LDS (nterms*Kc*N*4 <= 80 KB).
 // 512 threads = 8 waves; the block loads W once, then every wave streams its own 32-row tiles:
 //   global (float4, row-contiguous) -> registers -> wave-private LDS scratch [32][66] -> MFMA A fragments,

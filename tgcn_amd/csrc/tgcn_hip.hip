@@ -132,6 +132,7 @@ static int hop_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, in
                     const tgcn_dense* X, const tgcn_dense* Z, float alpha, float beta, const tgcn_dense* Z2, float gamma,
                     const tgcn_dense* Y, const tgcn_dense* P, void* workspace, size_t workspace_bytes, int long_rows_only) {
   if (!A || !S || !X || !X->ptr) TGCN_FAIL(TGCN_ERR_INVALID, "hop: null operand");
+  if (int drc = check_pointer_device(X->ptr, (hipStream_t)stream, "hop")) return drc;
   if ((!Y || !Y->ptr) && (!P || !P->ptr)) TGCN_FAIL(TGCN_ERR_INVALID, "hop: no output");
   if (A->n <= 0 || A->nnz < 0 || A->nnz >= (int64_t)INT32_MAX || A->n >= (int64_t)INT32_MAX)
     TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "hop: n=%lld nnz=%lld outside int32 index range", (long long)A->n, (long long)A->nnz);
@@ -208,8 +209,12 @@ struct ProjGather {
 // same function, so the fused relu + pool epilogue can never be requested from a kernel that does not have it.
 // project_variant: 0 auto (vector-ALU kernel for a few scalars per row, bf16x3 on large problems, else exact fp32: W-resident when the
 // weight fits, streaming otherwise), 1 exact-fp32 streaming, 2 exact-fp32 (W-resident with 16-row wave tiles when it fits), 3 bf16x3 always,
-// 4 exact fp32 auto, 5 vector-ALU kernel whenever it applies.
-enum ProjKernel { kProjNarrow, kProjResident, kProjX3, kProjX3Wide, kProjStream };
+// 4 exact fp32 auto, 5 vector-ALU kernel whenever it applies, 6 the streaming bf16x3 kernel whenever the shape has it (also below its row threshold).
+enum ProjKernel { kProjNarrow, kProjResident, kProjX3, kProjX3Wide, kProjStream, kProjX3Stream };
+constexpr int64_t kX3StreamMinRows = 32768;          // fewer rows: the tiled kernels (a persistent grid of 4096 waves wants >= a few tiles each)
+constexpr size_t kX3StreamMaxLds = 150 * 1024;       // the three bf16 planes of the whole weight in fragment order
+static inline int x3_stream_nt(int32_t N) { return N <= 16 ? 1 : (N <= 32 ? 2 : 4); }
+static inline size_t x3_stream_lds(int32_t Kc, int32_t N, int32_t nterms) { return (size_t)nterms * (Kc / 32) * x3_stream_nt(N) * 3 * 1024; }
 struct ProjChoice {
   ProjKernel kernel;
   int nt;            // 16-column tiles per workgroup of the W-resident kernel
@@ -217,7 +222,10 @@ struct ProjChoice {
   size_t wbytes;     // LDS image of the weight for the W-resident kernel
   bool pool_epilogue;   // the kernel can end in relu + max over consecutive rows (through its vector epilogue)
 };
-static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterms, bool vec4, bool vec_epilogue, bool has_rowmap, bool windows) {
+// stream_ok: the call has nothing the streaming kernel lacks (pool epilogue, fused last hop, accumulate, interleave, windows) -- project_impl knows,
+// the shape-only queries (pool / gather fusability) pass false: those forms live in project_x3_kernel.
+static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterms, bool vec4, bool vec_epilogue, bool has_rowmap, bool windows,
+                                 bool stream_ok = false, int32_t nbatch = 1) {
   ProjChoice c;
   const int pv = g_proj_variant.load();
   c.nt = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
@@ -238,6 +246,12 @@ static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterm
     return c;
   }
   const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
+  // rows of 32 / 64 floats, <= 64 output columns, whole weight resident as bf16 planes: the barrier-free streaming form
+  if (stream_ok && !windows && vec4 && vec_epilogue && (Kc == 32 || Kc == 64) && N <= 64 && x3_stream_lds(Kc, N, nterms) <= kX3StreamMaxLds &&
+      (pv == 6 || (pv == 0 && use_x3 && M * (int64_t)nbatch >= kX3StreamMinRows))) {
+    c.kernel = kProjX3Stream;
+    return c;
+  }
   if (c.wbytes <= (size_t)kResMaxWBytes && pv != 1 && !use_x3) {
     c.kernel = kProjResident;
     c.pool_epilogue = vec_epilogue;
@@ -298,6 +312,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
                         int32_t nbatch, const int64_t* a_bs, int64_t out_bs, int32_t pool, uint8_t* pool_idx, const ProjGather* gather) {
   if (nbatch < 1 || (nbatch > 1 && !a_bs)) TGCN_FAIL(TGCN_ERR_INVALID, "project: nbatch %d", nbatch);
   if (M <= 0 || Kc <= 0 || N <= 0 || nterms <= 0 || !a || !lda || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "project: bad argument");
+  if (int drc = check_pointer_device(out, (hipStream_t)stream, "project")) return drc;
   if (nterms > kMaxTerms) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: nterms %d > %d (chunk with accumulate=1)", nterms, kMaxTerms);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "project: bias_kind %d", bias_kind);
   if (interleave < 1 || n_vertices < 1) TGCN_FAIL(TGCN_ERR_INVALID, "project: interleave/n_vertices");
@@ -322,7 +337,10 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   p.Kc = Kc; p.N = N; p.nterms = nterms; p.bias_kind = bias_kind; p.accumulate = accumulate;
   p.vec_epilogue = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
                    (p.bias_cols % 4 == 0);
-  const ProjChoice choice = project_choose(M, Kc, N, nterms, vec4, p.vec_epilogue != 0, rowmap != nullptr, win_n != 0);
+  bool strides4 = (out_bs % 4 == 0);
+  if (nbatch > 1) for (int t = 0; t < nterms; ++t) strides4 = strides4 && (a_bs[t] % 4 == 0);
+  const bool stream_ok = pool <= 1 && !gather && !accumulate && interleave == 1 && win_n == 0 && strides4 && bias_cols < 0;
+  const ProjChoice choice = project_choose(M, Kc, N, nterms, vec4, p.vec_epilogue != 0, rowmap != nullptr, win_n != 0, stream_ok, nbatch);
   if (rowmap && interleave != 1 && choice.kernel != kProjNarrow)
     TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: a row map together with interleave is the vector-ALU kernel's form (nterms*Kc <= %d, N %% 4 == 0, M >= 4096)", kNarrowMaxK);
   if (pool > 1) {     // fused relu + max-pool epilogue: only where the dispatch takes a kernel that has it
@@ -343,7 +361,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   p.nbatch = 1;
   if (nbatch > 1) {
     // samples sharing the tile rows: inside project_x3_kernel<NT, true>, a host loop otherwise
-    if (choice.kernel == kProjX3 && vec4) {
+    if ((choice.kernel == kProjX3 && vec4) || choice.kernel == kProjX3Stream) {
       p.nbatch = nbatch; p.out_bs = out_bs;
       for (int t = 0; t < nterms; ++t) {
         p.a_bs[t] = a_bs[t];
@@ -380,6 +398,24 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
     ProfScope ps(TGCN_PROF_PROJECT, st);
     hipLaunchKernelGGL(project_narrow_kernel, dim3((unsigned)nb), dim3(kBlock), lds, st, p, iters);
     TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (narrow)");
+    return TGCN_OK;
+  }
+  if (choice.kernel == kProjX3Stream) {
+    const int snt = x3_stream_nt(N);
+    const size_t lds = x3_stream_lds(Kc, N, nterms);
+    const int64_t ntiles = (M + 15) / 16;
+    int64_t gx = (ntiles + 15) / 16;
+    if (gx > cu_count()) gx = cu_count();           // persistent: one 1024-thread workgroup per CU, waves take tiles round robin
+    ProfScope ps(TGCN_PROF_PROJECT, st);
+#define TGCN_PROJ_S(NTV, KTV)                                                                                              \
+  {                                                                                                                        \
+    allow_large_lds((const void*)project_x3_stream_kernel<NTV, KTV>, (int)kX3StreamMaxLds);                                \
+    hipLaunchKernelGGL((project_x3_stream_kernel<NTV, KTV>), dim3((unsigned)gx), dim3(1024), lds, st, p, ntiles);          \
+  }
+    if (Kc == 32) { if (snt == 1) TGCN_PROJ_S(1, 1) else if (snt == 2) TGCN_PROJ_S(2, 1) else TGCN_PROJ_S(4, 1) }
+    else { if (snt == 1) TGCN_PROJ_S(1, 2) else if (snt == 2) TGCN_PROJ_S(2, 2) else TGCN_PROJ_S(4, 2) }
+#undef TGCN_PROJ_S
+    TGCN_CHECK_LAUNCH("tgcn_cheb_project_f32 (bf16x3 streaming)");
     return TGCN_OK;
   }
   const bool use_x3 = choice.kernel == kProjX3 || choice.kernel == kProjX3Wide;
@@ -570,6 +606,7 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
                                      const float* x, const float* W, const float* fold, const float* bias, int32_t bias_kind,
                                      int32_t relu, int32_t pool, float* out, uint8_t* pool_idx) {
   if (!A || !x || !W || !out || K < 1 || q < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bad argument");
+  if (int drc = check_pointer_device(x, (hipStream_t)stream, "forward_small")) return drc;
   if (pool < 0 || pool > 255 || (pool > 0 && A->n % pool != 0) || (pool == 0 && relu)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: pool=%d relu=%d n=%lld", pool, relu, (long long)A->n);
   if (bias_kind < 0 || bias_kind > 2 || (bias_kind && !bias)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: bias_kind %d", bias_kind);
   if (fold && mode != 0) TGCN_FAIL(TGCN_ERR_INVALID, "forward_small: fold is for mode 0");
@@ -778,6 +815,7 @@ static int forward_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S
                         const float* bias, int32_t bias_kind, float* out, int32_t layout, int64_t q_chunk,
                         void* workspace, size_t workspace_bytes, int32_t pool, uint8_t* pool_idx) {
   if (!A || !S || !x || !W || !out) TGCN_FAIL(TGCN_ERR_INVALID, "forward: null operand");
+  if (int drc = check_pointer_device(x, (hipStream_t)stream, "forward")) return drc;
   if (K < 1 || q < 1 || n < 1 || C < 1 || N < 1 || n != A->n) TGCN_FAIL(TGCN_ERR_INVALID, "forward: bad shape (n=%lld, L is %lld)", (long long)n, (long long)A->n);
   if (mode != 0 && mode != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward: mode %d", mode);
   if (layout != 0 && layout != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward: layout %d", layout);
@@ -880,6 +918,7 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
                                   int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows, int64_t n_empty,
                                   const int32_t* compact_id, int64_t q_chunk, void* workspace, size_t workspace_bytes) {
   if (!A_first || !A_rest || !S || !x || !W || !out || !rows) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: null operand");
+  if (int drc = check_pointer_device(x, (hipStream_t)stream, "forward_compact")) return drc;
   const int64_t n_c = A_first->n;
   if (K < 2 || K > kMaxTerms || q < 1 || n < 1 || C < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: bad shape (K=%d)", K);
   if (A_rest->n != n_c || A_rest->nnz != A_first->nnz || n_c < 1 || n_empty < 0 || n_c + n_empty != n || (n_empty > 0 && !empty_rows))
@@ -996,6 +1035,7 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
                              int64_t n, int32_t C, int32_t N, const float* x, const float* Wcat, const float* bias,
                              int32_t bias_kind, float* out, void* workspace, size_t workspace_bytes) {
   if (!A || !S || !x || !Wcat || !out) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pf: null operand");
+  if (int drc = check_pointer_device(x, (hipStream_t)stream, "forward_pf")) return drc;
   if (K < 1 || q < 1 || n < 1 || C < 1 || N < 1 || n != A->n || q > 65535) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pf: bad shape");
   if (mode != 0 && mode != 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_pf: mode %d", mode);
   size_t z_bytes, y_bytes, off_part, total;

@@ -4,6 +4,7 @@ Every product, sum and axpy of the forward runs in libtgcn_hip.so (include/tgcn_
 memory, the stream and autograd bookkeeping.  There is no CPU fallback.
 """
 import ctypes as C
+import functools
 import threading
 
 import torch
@@ -14,6 +15,41 @@ SMALL_PATH = True   # developer switch (tools/): route small graphs through the 
 MODE_POWER = 0      # dense-L classes: Xt[k] = 2 L^k x - Xt[k-2]  (tgcn/nn/gcn.py:75-78,150-153,233-236)
 MODE_CHEBYSHEV = 1  # edge-list classes: Tx_k = 2 L Tx_{k-1} - Tx_{k-2}  (gcn.py:427-432,524-528)
 BIAS_NONE, BIAS_CHANNEL, BIAS_VERTEX_CHANNEL = 0, 1, 2
+
+
+def _cuda_device_of(a):
+    """device of a CUDA tensor / GraphOperand / CompactPlan argument (or of the first element of a list of them), else None"""
+    if isinstance(a, torch.Tensor):
+        return a.device if a.is_cuda else None
+    if isinstance(a, (list, tuple)):
+        return _cuda_device_of(a[0]) if a else None
+    d = getattr(a, "device", None)
+    return d if isinstance(d, torch.device) and d.type == "cuda" else None
+
+
+def _on_device(fn):
+    """Every entry that calls the library runs with the device of its DATA current, on that device's current stream -- the reference's
+    torch ops follow the tensor's device (tgcn/nn/gcn.py:141,147: `model.to('cuda:1')(x.to('cuda:1'))` works whatever device is
+    current, and nn.DataParallel's replicas rely on it, examples/pytorch_based/pytorch_hcp_tgcn.py:270-273), while a raw launch goes
+    to the calling thread's current device.  Arguments on two different devices are refused here (the kernels would dereference a
+    foreign pointer); the C ABI checks the same against hipGetDevice (common.h: check_pointer_device)."""
+    @functools.wraps(fn)
+    def on_device(*args, **kw):
+        dev = None
+        for a in args:
+            d = _cuda_device_of(a)
+            if d is None:
+                continue
+            if dev is None:
+                dev = d
+            elif d != dev:
+                raise _lib.TgcnError("tgcn_amd.%s: arguments on two devices (%s and %s) -- move the input, the parameters and the operand to one device"
+                                     % (fn.__name__, dev, d))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return on_device
 
 
 def _dense(t):
@@ -31,6 +67,7 @@ def _aligned16(C_row, *tensors):
 
 
 # ----------------------------------------------------------------------------------------- single ops
+@_on_device
 def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=None, z2=None, gamma=0.0):
     """One hop:  S = L x;  y = alpha*S + beta*z (+ gamma*z2);  optionally also S.  x: (nb, op.n_cols, C); y, z, z2, S:
     (nb, op.n, C); any of them may be a strided view as long as the last dim is contiguous.  Returns y (and S when want_p).
@@ -67,6 +104,7 @@ def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=No
     return (y, p) if want_p else y
 
 
+@_on_device
 def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
     """out[r(m)] = sum_t terms[t][m, :] @ W[t] + bias; terms: list of (M, Kc) contiguous; W: (T, Kc, N)."""
     _lib.require_device(W, *terms)
@@ -90,6 +128,7 @@ def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
     return out
 
 
+@_on_device
 def csr_sddmm(op, rows3, cols3, alpha=1.0, out=None, accumulate=False):
     """dval[e] (+)= alpha * sum_b sum_c rows3[b, row(e), c] * cols3[b, col(e), c] over the stored entries of `op`, in CSR order -> (nnz,).
     The gradient of S = L X w.r.t. the values of L is csr_sddmm(op, dS, X) (tgcn_csr_sddmm_f32)."""
@@ -110,12 +149,14 @@ class SpmmFn(torch.autograd.Function):
     product <g[row(e)], matrix[col(e)]> in CSR order (csr_sddmm) -- the reference's spmm* are differentiable in both (gcn.py:296-308)."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, matrix3, values_csr, op):
         ctx.op = op
         ctx.save_for_backward(matrix3)
         return csr_hop(op, matrix3)
 
     @staticmethod
+    @_on_device
     def backward(ctx, g):
         (matrix3,) = ctx.saved_tensors
         g = g.contiguous()
@@ -124,6 +165,7 @@ class SpmmFn(torch.autograd.Function):
         return gm, gv, None
 
 
+@_on_device
 def chebyshev_values_grad(op, x3, W_kcn, g):
     """d loss / d values (CSR order) of the true-recurrence layer out = sum_k T_k W_k, T_1 = L x, T_k = 2 L T_{k-1} - T_{k-2} (ChebConv /
     ChebTimeConv: lap_e = -deg^-1/2[row] w_e deg^-1/2[col] is differentiable in w_e in the reference, tgcn/nn/gcn.py:413,510).
@@ -149,6 +191,7 @@ def chebyshev_values_grad(op, x3, W_kcn, g):
     return dval
 
 
+@_on_device
 def _windows_forward(op, x3, W, bias, bias_kind, mode):
     """x3 (S, n, T) fp32 contiguous, W (K, H, N) in the WORKING basis (folded for MODE_POWER) -> (out, stack (K, S, n, T))"""
     L = _lib.lib()
@@ -173,6 +216,7 @@ class ChebWindowsFn(torch.autograd.Function):
     folded by Horner (mode 0) / Clenshaw (mode 1) hops on L^T exactly as in layer_backward; dW from the same entry point."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, series, weight_khg, bias, op, mode, bias_kind):
         x3 = series.float().contiguous()
         W = weight_khg.float().contiguous()
@@ -187,6 +231,7 @@ class ChebWindowsFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, g):
         x3, Wt = ctx.saved_tensors
         S, n, T = x3.shape
@@ -240,6 +285,7 @@ def cheb_time_windows(op, series, weight_khg, bias, bias_kind, mode=MODE_POWER):
     return ChebWindowsFn.apply(series, weight_khg, bias, op, mode, bias_kind)
 
 
+@_on_device
 def cheb_wgrad(terms, g2d):
     """dW[t] = terms[t]^T @ g2d  ->  (T, Kc, N); terms: list of (M, Kc) views with contiguous rows, g2d: (M, N)."""
     _lib.require_device(g2d, *terms)
@@ -272,6 +318,7 @@ def choose_q_chunk(q, n, C_row):
     return int(max(1, min(q, (64 << 20) // max(per_q, 1))))
 
 
+@_on_device
 def cheb_forward_raw(op, x3, Wt, bias, bias_kind, mode, K, layout=None, q_chunk=None):
     """Fused layer forward through tgcn_cheb_forward_f32.  x3: (q, n, C) contiguous; Wt: (K*C, N)."""
     _lib.require_device(x3, Wt, bias)
@@ -296,6 +343,7 @@ def cheb_forward_raw(op, x3, Wt, bias, bias_kind, mode, K, layout=None, q_chunk=
     return out
 
 
+@_on_device
 def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
     """Mode-0 forward on an operand with structurally empty rows (graph.CompactPlan) through tgcn_cheb_forward_compact_f32:
     hop tensors only for the vertices that have entries.  x3: (q, n, C) contiguous; Wt: (K*C, N) folded."""
@@ -376,6 +424,7 @@ def _compact_hop(op, X, Y, plan, z=None, alpha=1.0, beta=0.0):
         csr_hop(op, X[sl], z=None if z is None else z[sl, :n_c], alpha=alpha, beta=beta, out=Y[sl, :n_c])
 
 
+@_on_device
 def compact_terms(plan, x3, K, mode):
     """The K terms of the layer's basis with hop tensors for the plan's n_c kept vertices only.
     mode 0: [x3, P_1, ..., P_{K-1}], P_k = L^k x (monomials: the basis of the FOLDED weight); term 0 is x itself in the caller's labels.
@@ -412,6 +461,7 @@ def left_out_weight(W_kcn, mode):
     return (W_kcn * sign.view(K, 1, 1)).sum(0).contiguous()
 
 
+@_on_device
 def project_mapped(terms, term_bs, W2d, bias, bias_kind, n_vertices, rowmap, mapped_terms, q, out, interleave=1):
     """out[b, rowmap[m]] = sum_t terms[t][b, row_t(m)] @ W[t] + bias through tgcn_cheb_project_mapped_f32; terms: tensors whose sample b starts
     term_bs[t] floats after sample b-1; W2d: (T*Kc, N); out: (q, n_vertices, N) contiguous.
@@ -431,6 +481,7 @@ def project_mapped(terms, term_bs, W2d, bias, bias_kind, n_vertices, rowmap, map
     return out
 
 
+@_on_device
 def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, terms=None):
     """Layer forward with compact hop tensors from primitive calls of the library (hops on the plan's operands, two row-mapped projections):
     the form the training forward / backward and the Chebyshev-recurrence classes use (inference of the dense-L classes takes the one-call
@@ -468,6 +519,7 @@ def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, terms=None):
     return out, terms
 
 
+@_on_device
 def compact_wgrad(plan, x3, terms, g, mode):
     """dW (K, C, N) in the working basis from compact terms: the kept rows of g are gathered once (g_c), term k >= 1 contracts with them;
     the left-out vertices enter through x only -- term 0 for mode 0, and with alternating signs at every even k for mode 1 (T_k[i] = +-x[i])."""
@@ -488,6 +540,7 @@ def compact_wgrad(plan, x3, terms, g, mode):
     return dW
 
 
+@_on_device
 def cheb_forward_pool(op, x3, Wt, bias, bias_kind, mode, K, pool, z, idx, layout=None, q_chunk=None):
     """relu + max-pool fused layer on the hops-then-projection path (tgcn_cheb_forward_pool_f32) into z (q, n/pool, N) and the
     arg-max bytes idx.  x3: (q, n, C) contiguous; Wt: (K*C, N) in the working basis."""
@@ -523,6 +576,7 @@ def pool_epilogue_is_fused(op, q, Crow, N, K, pool, layout=None, q_chunk=None):
     return L.tgcn_cheb_forward_pool_workspace_bytes(C.byref(sched.struct), K, q, op.n, Crow, N, layout, q_chunk, pool) < base + q * op.n * N * 4
 
 
+@_on_device
 def cheb_stack(op, x3, K, mode, _operand_labels=False):
     """The (K, q, n, C) stack `_chebyshev` / `_time_chebyshev` return (gcn.py:52-79,126-154,208-237), or the
     true-recurrence stack for mode 1.  Materialising path: every hop writes its slice of the stack."""
@@ -568,6 +622,7 @@ def _power_fold_matrix(K, device=None, dtype=torch.float32):
     return c.to(device=device, dtype=dtype)
 
 
+@_on_device
 def fold_weight(fold, W, transpose=False):
     """W'[j] = sum_k fold[k, j] W[k]  (transpose: sum_k fold[j, k] W[k]) for a (K, C, N) weight, in libtgcn_hip.so: the
     forward path issues no vendor-library GEMM"""
@@ -590,6 +645,7 @@ def small_path_tile(op, C_row, mode, pool=False):
     return fn(op.n, op.nnz, int(C_row), int(mode))
 
 
+@_on_device
 def cheb_forward_small(op, x3, W_kcn, fold, bias, bias_kind, mode):
     """Whole layer in one launch (tgcn_cheb_forward_small_f32).  W_kcn: (K, C, N) RAW weight when `fold` is given."""
     _lib.require_device(x3, W_kcn, bias, fold)
@@ -608,6 +664,7 @@ def small_basis_tile(op, C_row, mode):
     return _lib.lib().tgcn_cheb_basis_small_supported(op.n, op.nnz, int(C_row), int(mode))
 
 
+@_on_device
 def cheb_basis_small(op, x3, K, mode):
     """Terms of the layer's basis as a list of K (q, n, C) tensors (term 0 is x3 itself): monomials L^k x for
     MODE_POWER (the basis of the folded weight), Chebyshev T_k x for MODE_CHEBYSHEV.  One launch."""
@@ -622,6 +679,7 @@ def cheb_basis_small(op, x3, K, mode):
     return [x3] + [stack[k] for k in range(K - 1)]
 
 
+@_on_device
 def cheb_forward_pf(op, x3, Wt_kcn, bias, bias_kind, mode):
     """Project-first form (tgcn_cheb_forward_pf_f32): ONE projection x . [W_0 | ... | W_{K-1}], then Horner / Clenshaw
     on the (q, n, N) results.  Wt_kcn: (K, C, N), already folded for MODE_POWER."""
@@ -650,6 +708,7 @@ def use_project_first(q, n, C_row, N):
     return PROJECT_FIRST and 2 * N <= C_row and q <= 65535
 
 
+@_on_device
 def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     """Forward of the layer on whichever path fits the shape (all in libtgcn_hip.so): the one-launch LDS kernel for
     small graphs, project-first for wide inputs / narrow outputs, hops-then-projection otherwise."""
@@ -667,6 +726,7 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
 
 
+@_on_device
 def relayout_qnc_to_nqc(x3):
     """(q, n, C) -> (n, q, C) contiguous: the LDS-tiled transpose kernel for C <= 32, torch otherwise."""
     q, n, Crow = x3.shape
@@ -681,6 +741,7 @@ def relayout_qnc_to_nqc(x3):
 KEEP_BASIS_BYTES = 2 << 30    # training on the hops-then-projection path keeps the hop tensors for the backward up to this size
 
 
+@_on_device
 def forward_keeping_basis(op, x3, Wt, bias, bias_kind, mode):
     """Hops-then-projection forward that hands the K hop tensors to the caller (they ARE the basis the weight gradient
     needs: monomials L^k x for the folded weight, Chebyshev T_k x for mode 1), instead of recomputing them in backward.
@@ -707,6 +768,7 @@ class ChebLayerFn(torch.autograd.Function):
     small-graph path, by tgcn_fold_weight_f32 otherwise; backward applies the transposed fold to the weight gradient."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x3, W, bias, op, mode, bias_kind, grad_mode=True, values=None):
         # `values`: the operand's stored values in CSR order as a tensor of the autograd graph (learnable edge weights of ChebConv /
         # ChebTimeConv).  The forward computes with the values packed in `op` (equal by construction); the tensor only receives the gradient.
@@ -740,6 +802,7 @@ class ChebLayerFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, g):
         x3, W = ctx.saved_tensors
         gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad,
@@ -749,6 +812,7 @@ class ChebLayerFn(torch.autograd.Function):
         return gx, gW, gb, None, None, None, None, gv
 
 
+@_on_device
 def _monomial_stack(op, x3, K):
     st = torch.empty((K,) + tuple(x3.shape), dtype=torch.float32, device=x3.device)
     st[0].copy_(x3)
@@ -789,6 +853,7 @@ def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode, values=None):
     return out if op.perm is None else out.index_select(1, op.inv_perm)
 
 
+@_on_device
 def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis=None):
     """Gradients of the layer w.r.t. (x3, W, bias).  All contractions run in libtgcn_hip.so: the basis is recomputed
     with the hop kernel, dW is the MFMA weight-gradient kernel, G = g W^T is the projection kernel with the transposed
@@ -871,6 +936,7 @@ class ChebReluPoolFn(torch.autograd.Function):
     small graphs (the layer output never reaches HBM), as one extra pass otherwise."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x3, W, bias, op, mode, bias_kind, pool):
         K, Crow, N = W.shape
         x3 = x3.contiguous()
@@ -904,6 +970,7 @@ class ChebReluPoolFn(torch.autograd.Function):
         return z
 
     @staticmethod
+    @_on_device
     def backward(ctx, gz):
         x3, W, z, idx = ctx.saved_tensors
         q, n, _ = x3.shape
@@ -929,6 +996,7 @@ class ReluPoolFn(torch.autograd.Function):
     """z = max over `pool` consecutive vertices of relu(y) as its own pass (tgcn_relu_pool_f32 / _bwd)."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, y, pool):
         _lib.require_device(y)
         y = y.float().contiguous()
@@ -942,6 +1010,7 @@ class ReluPoolFn(torch.autograd.Function):
         return z
 
     @staticmethod
+    @_on_device
     def backward(ctx, gz):
         z, idx = ctx.saved_tensors
         q, n, N = ctx.shape
@@ -951,6 +1020,7 @@ class ReluPoolFn(torch.autograd.Function):
         return gy, None
 
 
+@_on_device
 def pack_rows(src, idx, out):
     """out[i] = src[idx[i]] for a (rows, C) view with contiguous rows (halo messages of the vertex-sharded layer)"""
     _lib.require_device(src, idx, out)
@@ -963,6 +1033,7 @@ def pack_rows(src, idx, out):
 # ----------------------------------------------------------------------------------------- pooling
 class PoolMaxFn(torch.autograd.Function):
     @staticmethod
+    @_on_device
     def forward(ctx, x, p):
         _lib.require_device(x)
         x = x.float().contiguous()       # the kernel reads fp32; the reference's torch.max takes any dtype (gcn.py:246-255)
@@ -975,6 +1046,7 @@ class PoolMaxFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         q, n, f = ctx.shape

@@ -195,6 +195,7 @@ class CompactPlan:
 
     def __init__(self, op, keep, kind="rows"):
         dev = op.device
+        self.device = dev
         self.kind = kind                            # "rows": keep = rows with entries; "closed": also every vertex an entry points at
         self.n = op.n
         rows = keep.nonzero().flatten()
