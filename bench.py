@@ -144,6 +144,37 @@ def measured_copy_gbps(device, nbytes=2 << 30):
     return best
 
 
+def gather_ceiling(op, plan, C_row, device, fold=4096, reps=3):
+    """The shipped hop_kernel on THIS operand's own rows, row lengths, entry order and schedule rules, with every column folded into `fold`
+    rows of X spread evenly over the table (column c -> (c % fold) * (n_cols // fold)): all gathers then hit an L2-resident set (4096 rows of
+    256 B = 1 MB per XCD), which is the most ANY locality scheme -- reordering, blocking, cache policy -- could make of this graph with this
+    kernel.  One untimed launch, then `reps` timed ones (hipEvents of the library around the launch), outside the timed steps.
+    -> (median ms per launch, fix-up ms)"""
+    from tgcn_amd import _lib, functional as _F
+    from tgcn_amd.graph import GraphOperand
+    src = plan.rest if plan is not None else op            # the operand hops 2..K-1 run on (compact ids), or the plain one
+    row, col, val = src.coo()
+    n_cols = src.n_cols
+    col = (col % fold) * max(1, n_cols // fold)
+    fop = GraphOperand.from_coo(src.n, row, col, val, device, n_cols=n_cols)
+    del row, col, val
+    g = torch.Generator(device=device).manual_seed(99)
+    x1 = torch.randn((1, n_cols, C_row), device=device, generator=g)
+    y1 = torch.empty((1, src.n, C_row), device=device)
+    _F.csr_hop(fop, x1, out=y1)
+    torch.cuda.synchronize()
+    _lib.profile_start(64)
+    for _ in range(reps):
+        _F.csr_hop(fop, x1, out=y1)
+    torch.cuda.synchronize()
+    prof = _lib.profile_stop(64)
+    hop = sorted(ms for kind, ms in prof if kind == 0)
+    fix = sorted(ms for kind, ms in prof if kind == 1)
+    del fop, x1, y1
+    torch.cuda.empty_cache()
+    return hop[len(hop) // 2], (fix[len(fix) // 2] if fix else 0.0)
+
+
 def scipy_baseline(op, spec, x, cols=8):
     """Single-thread scipy CSR, like the reference's numpy path (gcn/graph.py:256-265: Xt[k] = 2 L^k X - Xt[k-2] with
     scipy's .dot): the K-hop recursion of oracle.cheb_oracle.graph_chebyshev on `cols` of the C_in*H columns of ONE sample."""
@@ -466,6 +497,7 @@ def main():
     ap.add_argument("--vertices", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
     ap.add_argument("--entries", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip roofline.gather_ceiling_ms (one extra operand build + 4 hop launches after the timed steps)")
     ap.add_argument("--shard", default="time", choices=["time", "vertex", "hybrid"], help="N > 1: time steps split over the ranks (no collective); vertex rows per rank with a halo / all-gather exchange per hop; hybrid: --vertex-shards ranks share a graph, groups split the time steps")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1, time sharding: strong = the workload's q time steps split over the ranks (default); weak = q time steps per rank")
     ap.add_argument("--vertex-shards", type=int, default=2, help="ranks per graph copy for --shard hybrid")
@@ -657,6 +689,19 @@ def main():
         if hop_long_ms:
             roofline["note"] = ("last hop fused into the projection: %d of the %d hop launches per step cover the rows above the threshold only and are NOT in "
                                 "mean_launch_ms; frac is for the full hop launches" % (len(hop_long_ms) // args.steps, n_hop_launches))
+        if world == 1 and not vertex_mode and not pf_path and not small_ms and args.workload in ("cfg5", "cfg5n") and not args.no_ceiling:
+            # how far the measured launch is from the best any locality scheme could reach, in the driver's record
+            try:
+                layout1 = _F.choose_layout(q, op.n, C_row) == 1
+                ceil_ms, ceil_fix = gather_ceiling(op, plan_r, q * C_row if layout1 else C_row, device)
+                roofline["gather_ceiling_ms"] = round(ceil_ms, 4)
+                roofline["frac_of_gather_ceiling"] = round(ceil_ms / mean_ms, 4)
+                roofline["gather_ceiling_note"] = ("the same hop_kernel on the same rows / row lengths / schedule rules with every column folded into 4096 rows of X "
+                                                   "(all gathers L2 hits): the bound of ANY locality scheme for this kernel on this graph; measured after the timed "
+                                                   "steps, 1 untimed + 3 timed launches (median); its fix-up %.3f ms" % ceil_fix)
+            except Exception as e:      # noqa: BLE001 -- a diagnostic never costs the headline
+                roofline["gather_ceiling_ms"] = None
+                roofline["gather_ceiling_note"] = "not measured: %s: %s" % (type(e).__name__, str(e)[:200])
         step_s = dt / args.steps
         roofline["whole_step"] = dict(bytes=int(bytes_recursion), achieved=round(bytes_recursion / step_s / 1e9, 1), unit="GB/s",
                                       frac=round(bytes_recursion / step_s / 1e9 / HBM_PEAK_GBPS, 4),

@@ -72,6 +72,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // Tuning bits of the hop kernel (NTM): which accesses carry the non-temporal hint, and ev prefetch.
 constexpr int kNtEdges = 1, kNtStores = 2, kNtPartials = 4;
+// kNtColdGather (round-5 experiment, tools/hop_bench.py --cold-last RANK --cold-nt): an entry whose column has bit 31 set points at a COLD row
+// of X (outside the RANK most referenced); its gather carries the non-temporal hint so that the lines that miss anyway do not evict the hub
+// rows from the 4-MB L2s.  The flag is part of the experiment's operand, not of the ABI: no shipped operand sets it.
+constexpr int kNtColdGather = 8;
 
 template <int VEC>
 __device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[VEC]) {
@@ -189,7 +193,14 @@ __device__ __forceinline__ void accum_multi(const tgcn_edge* __restrict__ ev, co
             vv[rr][u] = __int_as_float(group_bcast<LPR>(__float_as_int(my_v[rr]), j0 + u));   // 0 past the end of the row
 #pragma unroll
             for (int i = 0; i < VEC; ++i) xv[rr][u][i] = 0.f;
-            if (j0 + u < cnt[rr]) load_vec<VEC>(Xc + (int64_t)c * ldx, xv[rr][u]);
+            if constexpr (NTM & kNtColdGather) {
+              if (j0 + u < cnt[rr]) {
+                if (c < 0) load_vec_nt<VEC>(Xc + (int64_t)(c & 0x7fffffff) * ldx, xv[rr][u]);
+                else load_vec<VEC>(Xc + (int64_t)c * ldx, xv[rr][u]);
+              }
+            } else {
+              if (j0 + u < cnt[rr]) load_vec<VEC>(Xc + (int64_t)c * ldx, xv[rr][u]);
+            }
           }
 #pragma unroll
         for (int rr = 0; rr < R; ++rr)
@@ -411,6 +422,8 @@ inline bool launch_hop_variant(int lpr, hipStream_t st, const HopParams& p, dim3
       case 2: launch_hop<16, 4, 8, 1, kNtEdges>(st, p, grid); return true;
       case 3: launch_hop<16, 4, 8, 1, kNtEdges | kNtStores>(st, p, grid); return true;
       case 4: launch_hop<16, 4, 8, 1, 0>(st, p, grid); return true;
+      case 5: launch_hop<16, 4, 8, 1, kNtEdges | kNtStores | kNtPartials | kNtColdGather>(st, p, grid); return true;   // experiment: nt gathers of flagged (cold) columns
+      case 6: launch_hop<16, 4, 8, 1, kNtEdges | kNtStores | kNtPartials>(st, p, grid); return true;                   // the shipped streaming form, forced
       default: return false;
     }
   }

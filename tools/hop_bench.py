@@ -39,7 +39,10 @@ def main():
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     ap.add_argument("--cold-last", type=int, default=None, help="reorder the entries inside every row: entries whose column is among the RANK most referenced "
                     "columns first (in column order), the others behind them (in column order) -- a gather instruction then carries lines of one latency class")
+    ap.add_argument("--cold-nt", action="store_true", help="with --cold-last: variant 5 runs on a copy of the entries whose COLD columns carry bit 31 "
+                    "(hop_kernel gathers them with the non-temporal hint); every other variant runs on the plain entries")
     args = ap.parse_args()
+    assert not args.cold_nt or args.cold_last is not None, "--cold-nt needs --cold-last RANK"
     from tools import synth
     from tgcn_amd import _lib, graph, functional as F
     if args.row_thresh:
@@ -90,8 +93,13 @@ def main():
         order = torch.argsort(rows * 2 + cold.long(), stable=True)
         print("cold-last: %d of %d entries point at a column outside the %d most referenced" % (int(cold.sum()), op.nnz, args.cold_last), flush=True)
         edges2 = op.edges[: op.nnz][order].contiguous()
+        cold_sorted = cold[order]
         del cols, pop, rank, cold, rows, order
         op = graph.GraphOperand._from_packed(op.n, op.rowptr, edges2, op.nnz, n_cols=op.n_cols)
+        if args.cold_nt:
+            flagged = edges2.clone()
+            flagged[cold_sorted, 0] |= -2147483648          # bit 31 of the column: "cold" (kNtColdGather in csrc/hop.h masks it off)
+        del cold_sorted
     lanes = _lib.lib().tgcn_hop_lanes_per_row(args.C // args.split, 1)
     scheds = {m: graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, seg_mode=m, n_cols=op.n_cols) for m in sorted(set(int(m) for m in args.seg_modes.split(",")))}
     for m, sm in scheds.items():
@@ -114,6 +122,8 @@ def main():
             _lib.check(L.tgcn_set_tuning(b"hop_seg_remap", v[4]))
             _lib.check(L.tgcn_set_tuning(b"hop_mix", v[5]))
             op._sched[lanes] = scheds[v[3]]
+            if args.cold_nt:      # ONLY variant 5 understands flagged columns: every other kernel would read out of bounds
+                op.struct.edges = flagged.data_ptr() if v[0] == 5 else op.edges.data_ptr()
             _lib.profile_start(16)
             cs = args.C // args.split
             for sp in range(args.split):
