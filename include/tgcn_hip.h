@@ -30,7 +30,7 @@ extern "C" {
 #define TGCN_ERR_WORKSPACE (-3)   /* caller workspace too small */
 #define TGCN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
 
-#define TGCN_ABI_VERSION 5
+#define TGCN_ABI_VERSION 6
 
 /* One stored entry of the sparse operand: 8 bytes, read with a single load. */
 typedef struct tgcn_edge {
@@ -241,6 +241,11 @@ int tgcn_csr_hop_f64(void* stream, int64_t n, const int32_t* rowptr, const int32
  * adjoint, for the weight gradient).  fold: K x K device matrix (tgcn_amd/functional.py::power_fold_matrix). */
 int tgcn_fold_weight_f32(void* stream, int32_t K, int64_t CN, const float* fold, const float* W, float* out, int32_t transpose);
 
+/* Re-layouts of a (K, C, N) layer weight for the drivers (ABI v6; the host side issues no torch permute on the path):
+ *   kind 0: (C, K*N), out[c, k*N + n] = W[k, c, n]  -- Wcat of tgcn_cheb_forward_pf_f32;
+ *   kind 1: (K, N, C), W_k^T -- the input gradient as a layer on (L^T, g, W^T);   kind 2: (N, K*C) -- G = g [W_0^T | ... | W_{K-1}^T]. */
+int tgcn_weight_layout_f32(void* stream, int32_t K, int32_t C, int32_t N, const float* W, float* out, int32_t kind);
+
 /* Stacked-hop dense projection (gcn.py:39,113,194 einsum; :420-431 / :519-527 per-hop matmul):
  *   out[r(m), :] (+)= sum_t A_t[m, 0:Kc] . W[t*Kc:(t+1)*Kc, 0:N] + bias
  * A_t: M x Kc with row stride lda[t]; W: (nterms*Kc) x N contiguous; fp32 MFMA, fp32 accumulate.
@@ -291,7 +296,8 @@ size_t tgcn_cheb_wgrad_workspace_bytes(int64_t M, int32_t Kc, int32_t N, int32_t
 int tgcn_cheb_wgrad_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
                         const int64_t* lda, const float* G, int64_t ldg, float* dW, void* workspace, size_t workspace_bytes);
 
-/* (Q, n, C) -> (n, Q, C) re-layout so that short per-sample rows become one long row per vertex. */
+/* (Q, n, C) -> (n, Q, C) re-layout so that short per-sample rows become one long row per vertex (LDS-tiled transpose for C <= 32, a
+ * coalesced row copy for wider rows). */
 int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int64_t Q, int64_t n, int32_t C);
 
 /* Whole layer forward: K-1 hops + projection, enqueued on `stream` (capturable in a hipGraph).
@@ -325,6 +331,27 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
                                   int32_t K, int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W,
                                   const float* bias, int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows,
                                   int64_t n_empty, const int32_t* compact_id, int64_t q_chunk, void* workspace, size_t workspace_bytes);
+
+/* The compacted layer in general form (ABI v6): BOTH recurrences, and optionally the hop tensors handed back to the caller.
+ *   mode 0  as tgcn_cheb_forward_compact_f32 (which is this function with mode 0, W_left = NULL, keep_terms = NULL).
+ *   mode 1  true Chebyshev recurrence (ChebConv / ChebTimeConv, tgcn/nn/gcn.py:420-432, :519-528) on compact hop tensors: the kept
+ *           vertices must be CLOSED -- every vertex with entries and every vertex an entry points at -- so that a left-out vertex is
+ *           isolated and T_k[i] = x[i], 0, -x[i], 0, ...: out[i] = x[i] W_left + bias with W_left = W_0 - W_2 + W_4 - ... (C x N, the
+ *           caller folds it: tgcn_fold_weight_f32 with the sign column).  T_0 = the kept rows of x (packed by the driver), T_1 = A_rest T_0,
+ *           T_k = 2 A_rest T_{k-1} - T_{k-2}; A_first is not used.  W: (K*C) x N in the reference basis.
+ *   W_left  (nullable for mode 0: the first C rows of W, i.e. W'_0)  the C x N matrix of the left-out vertices.
+ *   keep_terms (nullable)  caller memory for the hop tensors, [T][q][n_c + 1][C] floats contiguous, T = K-1 (mode 0: terms 1..K-1) or
+ *           K (mode 1: terms 0..K-1); row n_c of every sample is zeroed by the driver.  They are exactly the basis the weight gradient
+ *           contracts with g (the training forward keeps them instead of recomputing K-1 hops in backward); all q samples are then one
+ *           pass and the workspace holds the long-row scratch only.
+ * One C call per layer forward replaces the host-side pipeline of K hops + 2 projections (functional.compact_forward before round 5). */
+size_t tgcn_cheb_compact_layer_workspace_bytes(const tgcn_csr_sched* sched, int32_t mode, int32_t K, int64_t q, int64_t n_c, int32_t C,
+                                               int64_t q_chunk, int32_t keep_terms);
+int tgcn_cheb_compact_layer_f32(void* stream, const tgcn_csr* A_first, const tgcn_csr* A_rest, const tgcn_csr_sched* sched, int32_t mode,
+                                int32_t K, int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W, const float* W_left,
+                                const float* bias, int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows,
+                                int64_t n_empty, const int32_t* compact_id, int64_t q_chunk, float* keep_terms, void* workspace,
+                                size_t workspace_bytes);
 
 /* "Project first" form of the same layer for wide inputs and narrow outputs (N well below C = H*f, e.g.
  * TGCNCheb_H(L, 1, 32, K, 1200)): Z = x . Wcat for all K terms in ONE projection (Wcat: C x (K*N), column block j =

@@ -138,7 +138,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib().tgcn_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib().tgcn_abi_version() == _lib.ABI_VERSION == 6
 
 
 def _kernel_resources():

@@ -99,6 +99,10 @@ SIGNATURES = {
     "tgcn_cheb_forward_compact_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32,
                                                 C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P,
                                                 C.c_int64, _P, C.c_int64, _P, C.c_size_t]),
+    "tgcn_cheb_compact_layer_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int32]),
+    "tgcn_cheb_compact_layer_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32,
+                                              C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P,
+                                              C.c_int64, _P, C.c_int64, _P, _P, C.c_size_t]),
     "tgcn_cheb_forward_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_basis_small_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tgcn_cheb_forward_small_pool_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
@@ -114,6 +118,7 @@ SIGNATURES = {
     "tgcn_cheb_windows_backward_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P,
                                                  _P, C.c_size_t]),
     "tgcn_fold_weight_f32": (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32]),
+    "tgcn_weight_layout_f32": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "tgcn_csr_hop_f64": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "tgcn_pack_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
     "tgcn_pool_max_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
@@ -121,7 +126,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5      # include/tgcn_hip.h: TGCN_ABI_VERSION
+ABI_VERSION = 6      # include/tgcn_hip.h: TGCN_ABI_VERSION
 
 
 def source_hash():

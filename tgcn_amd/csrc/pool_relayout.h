@@ -111,6 +111,38 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const float* __restri
   }
 }
 
+// out[r, :] = src[idx[r], :] with int32 row ids and 16-byte pieces when the rows allow it: T_0 of the compacted Chebyshev layer (the kept rows of
+// x packed to compact ids, tgcn_cheb_compact_layer_f32 mode 1) and the wide-row form of tgcn_pack_rows_f32
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gather_rows_i32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                                 int64_t nrows, int32_t C, int64_t ld_src) {
+  const int per = C / VEC;
+  const int64_t total = nrows * per;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / per;
+    const int c = (int)(i - r * per) * VEC;
+    float v[VEC];
+    load_vec<VEC>(src + (int64_t)idx[r] * ld_src + c, v);
+    store_vec<VEC>(out + r * C + c, v);
+  }
+}
+
+// (Q, n, C) -> (n, Q, C) for rows of more than 32 floats: every row is >= 128 contiguous bytes, so a plain row copy is already coalesced
+// (the LDS-tiled transpose above is for the short rows it was built for)
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void relayout_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t Q, int64_t n, int32_t C) {
+  const int per = C / VEC;
+  const int64_t total = Q * n * per;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t orow = i / per;                    // output row = vertex * Q + sample
+    const int c = (int)(i - orow * per) * VEC;
+    const int64_t v = orow / Q, b = orow - v * Q;
+    float t[VEC];
+    load_vec<VEC>(in + (b * n + v) * C + c, t);
+    store_vec<VEC>(out + orow * C + c, t);
+  }
+}
+
 // Sampled dense-dense product over the stored pattern: the gradient of a hop w.r.t. its operand VALUES (tgcn/nn/gcn.py:296-308, 413, 510: the
 // reference's gather / scale / scatter_add form is differentiable in `value` / `edge_weight`):
 //   dval[e] (+)= alpha * sum_b sum_c A[b, row(e), c] * B[b, col(e), c]          for every stored entry e
@@ -174,6 +206,22 @@ __global__ __launch_bounds__(kBlock) void fold_weight_kernel(const float* __rest
     for (int k = 0; k < K; ++k) a = fmaf(transpose ? fold[j * K + k] : fold[k * K + j], W[(int64_t)k * CN + i], a);
     out[(int64_t)j * CN + i] = a;
   }
+}
+
+// The three re-layouts of a (K, C, N) layer weight that the drivers take (tiny tensors; round 4 did them with torch permutes on the forward path):
+//   kind 0  (C, K*N)   out[c, k*N + n] = W[k, c, n]    column blocks W_0 | ... | W_{K-1}: the ONE projection of the project-first form
+//   kind 1  (K, N, C)  out[k, n, c]    = W[k, c, n]    W_k^T: the input gradient dx = sum_k T_k(L^T) g W_k^T run as a layer on (L^T, g, W^T)
+//   kind 2  (N, K*C)   out[n, k*C + c] = W[k, c, n]    G = g [W_0^T | ... | W_{K-1}^T] for all K terms in one projection
+__global__ __launch_bounds__(kBlock) void weight_layout_kernel(const float* __restrict__ W, float* __restrict__ out, int K, int C, int N, int kind) {
+  const int64_t total = (int64_t)K * C * N;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // index into W: (k, c, n)
+  if (i >= total) return;
+  const int n = (int)(i % N), c = (int)((i / N) % C), k = (int)(i / ((int64_t)N * C));
+  int64_t o;
+  if (kind == 0) o = ((int64_t)c * K + k) * N + n;
+  else if (kind == 1) o = ((int64_t)k * N + n) * C + c;
+  else o = ((int64_t)n * K + k) * C + c;
+  out[o] = W[i];
 }
 
 // ---- backward of the streaming time-window projection (tgcn_cheb_project_windows_f32):

@@ -546,7 +546,15 @@ int tgcn_cheb_wgrad_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
 
 int tgcn_relayout_qnc_to_nqc_f32(void* stream, const float* in, float* out, int64_t Q, int64_t n, int32_t C) {
   if (!in || !out || Q <= 0 || n <= 0 || C <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "relayout: bad argument");
-  if (C > 32) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "relayout: C=%d > 32", C);
+  if (C > 32) {       // wide rows: a coalesced row copy
+    const bool v4 = (C % 4 == 0) && (((uintptr_t)in & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    const int64_t units = Q * n * (v4 ? C / 4 : C);
+    ProfScope ps(TGCN_PROF_RELAYOUT, (hipStream_t)stream);
+    if (v4) hipLaunchKernelGGL((relayout_rows_kernel<4>), dim3(grid_1d(units)), dim3(kBlock), 0, (hipStream_t)stream, in, out, Q, n, C);
+    else hipLaunchKernelGGL((relayout_rows_kernel<1>), dim3(grid_1d(units)), dim3(kBlock), 0, (hipStream_t)stream, in, out, Q, n, C);
+    TGCN_CHECK_LAUNCH("tgcn_relayout_qnc_to_nqc_f32 (wide rows)");
+    return TGCN_OK;
+  }
   const int64_t gy = (Q + kRelT - 1) / kRelT;
   if (gy > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "relayout: Q too large");
   const int vt = relayout_vertex_tile(C);
@@ -896,82 +904,122 @@ static int forward_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S
   return TGCN_OK;
 }
 
-// Workspace of the compacted forward: K-1 hop tensors of qc x (n_c + 1) x C floats (row n_c of every sample is the zero row that
-// entries pointing at an empty vertex gather from), then the long-row scratch of one hop.
-static void cfwd_ws_layout(const tgcn_csr_sched* S, int32_t K, int64_t n_c, int32_t C, int64_t qc, size_t* hop_bytes, size_t* off_part,
-                           size_t* total) {
+// Workspace of the compacted layer: the hop tensors -- K-1 (mode 0: terms 1..K-1) or K (mode 1: T_0 = x packed to the kept rows, then
+// T_1..T_{K-1}) buffers of qc x (n_c + 1) x C floats (row n_c of every sample is the zero row that entries pointing at a left-out
+// vertex gather from) -- unless the caller keeps the terms in its own memory, then the long-row scratch of one hop.
+static int compact_nterm_bufs(int32_t mode, int32_t K) { return mode == 1 ? K : (K > 1 ? K - 1 : 0); }
+
+static void cfwd_ws_layout(const tgcn_csr_sched* S, int32_t mode, int32_t K, int64_t n_c, int32_t C, int64_t qc, int keep, size_t* hop_bytes,
+                           size_t* off_part, size_t* total) {
   *hop_bytes = align_up((size_t)qc * (size_t)(n_c + 1) * C * sizeof(float), 256) + 65 * 256;   // staggered like fwd_ws_layout
-  *off_part = (size_t)(K > 1 ? K - 1 : 0) * *hop_bytes;
+  *off_part = keep ? 0 : (size_t)compact_nterm_bufs(mode, K) * *hop_bytes;
   *total = *off_part + align_up(tgcn_csr_hop_workspace_bytes(S, 1, C, 1), 256);      // hops run one time step per launch
 }
 
-size_t tgcn_cheb_forward_compact_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n_c, int32_t C, int64_t q_chunk) {
-  if (!S || K < 2 || q < 1 || n_c < 1 || C < 1) return 0;
-  const int64_t qc = (q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
+size_t tgcn_cheb_compact_layer_workspace_bytes(const tgcn_csr_sched* S, int32_t mode, int32_t K, int64_t q, int64_t n_c, int32_t C, int64_t q_chunk,
+                                               int32_t keep_terms) {
+  if (!S || K < 2 || q < 1 || n_c < 1 || C < 1 || (mode != 0 && mode != 1)) return 0;
+  const int64_t qc = (keep_terms || q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
   size_t a, b, total;
-  cfwd_ws_layout(S, K, n_c, C, qc, &a, &b, &total);
+  cfwd_ws_layout(S, mode, K, n_c, C, qc, keep_terms != 0, &a, &b, &total);
   return total;
+}
+
+size_t tgcn_cheb_forward_compact_workspace_bytes(const tgcn_csr_sched* S, int32_t K, int64_t q, int64_t n_c, int32_t C, int64_t q_chunk) {
+  return tgcn_cheb_compact_layer_workspace_bytes(S, 0, K, q, n_c, C, q_chunk, 0);
 }
 
 int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const tgcn_csr* A_rest, const tgcn_csr_sched* S, int32_t K,
                                   int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W, const float* bias,
                                   int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows, int64_t n_empty,
                                   const int32_t* compact_id, int64_t q_chunk, void* workspace, size_t workspace_bytes) {
-  if (!A_first || !A_rest || !S || !x || !W || !out || !rows) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: null operand");
-  if (int drc = check_pointer_device(x, (hipStream_t)stream, "forward_compact")) return drc;
+  return tgcn_cheb_compact_layer_f32(stream, A_first, A_rest, S, 0, K, q, n, C, N, x, W, nullptr, bias, bias_kind, out, rows, empty_rows, n_empty,
+                                     compact_id, q_chunk, nullptr, workspace, workspace_bytes);
+}
+
+int tgcn_cheb_compact_layer_f32(void* stream, const tgcn_csr* A_first, const tgcn_csr* A_rest, const tgcn_csr_sched* S, int32_t mode, int32_t K,
+                                int64_t q, int64_t n, int32_t C, int32_t N, const float* x, const float* W, const float* W_left, const float* bias,
+                                int32_t bias_kind, float* out, const int32_t* rows, const int32_t* empty_rows, int64_t n_empty,
+                                const int32_t* compact_id, int64_t q_chunk, float* keep_terms, void* workspace, size_t workspace_bytes) {
+  if (!A_first || !A_rest || !S || !x || !W || !out || !rows) TGCN_FAIL(TGCN_ERR_INVALID, "compact_layer: null operand");
+  if (int drc = check_pointer_device(x, (hipStream_t)stream, "compact_layer")) return drc;
   const int64_t n_c = A_first->n;
-  if (K < 2 || K > kMaxTerms || q < 1 || n < 1 || C < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: bad shape (K=%d)", K);
+  if (mode != 0 && mode != 1) TGCN_FAIL(TGCN_ERR_INVALID, "compact_layer: mode %d", mode);
+  if (K < 2 || K > kMaxTerms || q < 1 || n < 1 || C < 1 || N < 1) TGCN_FAIL(TGCN_ERR_INVALID, "compact_layer: bad shape (K=%d)", K);
   if (A_rest->n != n_c || A_rest->nnz != A_first->nnz || n_c < 1 || n_empty < 0 || n_c + n_empty != n || (n_empty > 0 && !empty_rows))
-    TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: %lld compact + %lld empty rows for n=%lld", (long long)n_c, (long long)n_empty, (long long)n);
-  if ((C % 4 == 0 && ((uintptr_t)x & 15)) || ((uintptr_t)workspace & 15)) TGCN_FAIL(TGCN_ERR_INVALID, "forward_compact: x/workspace must be 16-byte aligned");
-  const int64_t qc = (q_chunk <= 0 || q_chunk > q) ? q : q_chunk;
-  if (qc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "forward_compact: q_chunk %lld", (long long)qc);
+    TGCN_FAIL(TGCN_ERR_INVALID, "compact_layer: %lld compact + %lld left-out rows for n=%lld", (long long)n_c, (long long)n_empty, (long long)n);
+  if (mode == 1 && n_empty > 0 && !W_left) TGCN_FAIL(TGCN_ERR_INVALID, "compact_layer: mode 1 needs W_left (W_0 - W_2 + W_4 - ...) for the left-out vertices");
+  if ((C % 4 == 0 && ((uintptr_t)x & 15)) || ((uintptr_t)workspace & 15) || ((uintptr_t)keep_terms & 15))
+    TGCN_FAIL(TGCN_ERR_INVALID, "compact_layer: x / workspace / keep_terms must be 16-byte aligned");
+  const int64_t qc = (keep_terms || q_chunk <= 0 || q_chunk > q) ? q : q_chunk;      // kept terms: every sample's hop tensors survive the call
+  if (qc > 65535) TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "compact_layer: %lld samples per pass", (long long)qc);
   size_t hop_bytes, off_part, total;
-  cfwd_ws_layout(S, K, n_c, C, qc, &hop_bytes, &off_part, &total);
-  if (!workspace || workspace_bytes < total) TGCN_FAIL(TGCN_ERR_WORKSPACE, "forward_compact: workspace %zu < %zu", workspace_bytes, total);
+  cfwd_ws_layout(S, mode, K, n_c, C, qc, keep_terms != nullptr, &hop_bytes, &off_part, &total);
+  if (!workspace || workspace_bytes < total) TGCN_FAIL(TGCN_ERR_WORKSPACE, "compact_layer: workspace %zu < %zu", workspace_bytes, total);
   char* ws = (char*)workspace;
   float* part = (float*)(ws + off_part);
   const size_t part_bytes = total - off_part;
   const int64_t bs_c = (n_c + 1) * (int64_t)C;            // sample stride of a compact hop tensor
-  auto hop_ptr = [&](int k) { return (float*)(ws + (size_t)(k - 1) * hop_bytes); };
+  const int k_first = mode == 1 ? 0 : 1;                  // first term that lives in a compact buffer
+  // term k of the pass: in the caller's buffer the terms are contiguous ([term][q][n_c + 1][C]), in the workspace staggered
+  auto hop_ptr = [&](int k) -> float* {
+    const int i = k - k_first;
+    return keep_terms ? keep_terms + (int64_t)i * q * bs_c : (float*)(ws + (size_t)i * hop_bytes);
+  };
   hipStream_t st = (hipStream_t)stream;
-  // the zero row of every hop tensor (gathered from by the next hop and, with compact_id, by the projection for the empty
+  // the zero row of every hop tensor (gathered from by the next hop and, with compact_id, by the projection for the left-out
   // vertices); no hop writes it, so once per call
-  for (int k = 1; k < K; ++k)
+  for (int k = k_first; k < K; ++k)
     if (hipMemset2DAsync(hop_ptr(k) + n_c * (int64_t)C, (size_t)bs_c * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)qc, st) != hipSuccess)
-      TGCN_FAIL(TGCN_ERR_LAUNCH, "forward_compact: memset failed");
+      TGCN_FAIL(TGCN_ERR_LAUNCH, "compact_layer: memset failed");
   const float* terms[kMaxTerms];
   int64_t ldas[kMaxTerms];
   for (int k = 0; k < K; ++k) ldas[k] = C;
   int rc;
   int64_t a_bs[kMaxTerms];
-  a_bs[0] = n * (int64_t)C;
+  a_bs[0] = mode == 1 ? bs_c : n * (int64_t)C;
   for (int k = 1; k < K; ++k) a_bs[k] = bs_c;
   // tgcn_set_tuning("fuse_last_hop", 1): last hop fused into the projection of the compact rows, where that projection is the bf16x3 kernel
   // with <= 64 output columns (with compact_proj = 1 the projection runs over all vertices instead).  Bitwise the unfused result; OFF by
-  // default: measured slower on cfg5
-  const bool fuse_last = g_fuse_last.load() && !(compact_id && g_compact_proj.load() == 1) && ((uintptr_t)x & 15) == 0 &&
+  // default: measured slower on cfg5 (docs/EXPERIMENTS.md A.4).  Mode 0 only.
+  const bool one_proj = mode == 0 && compact_id && g_compact_proj.load() == 1;
+  const bool fuse_last = mode == 0 && g_fuse_last.load() && !one_proj && ((uintptr_t)x & 15) == 0 &&
                          project_gather_fusable(n_c, C, N, K, true) && (N % 4 == 0) && (((uintptr_t)out & 15) == 0) &&
                          (!bias || ((uintptr_t)bias & 15) == 0);
+  const bool vec_rows = (C % 4 == 0) && (((uintptr_t)x & 15) == 0);
   for (int64_t q0 = 0; q0 < q; q0 += qc) {
     const int64_t qn = (q - q0 < qc) ? (q - q0) : qc;
     const float* x0 = x + q0 * n * C;
     // hops: one launch per hop and time step (a launch's gather working set stays one (n_c, C) slab).
+    // mode 0 (monomials of the folded weight): P_1 = A_first x (columns in the caller's labels), P_k = A_rest P_{k-1}.
+    // mode 1 (Chebyshev): T_0 = the kept rows of x, T_1 = A_rest T_0, T_k = 2 A_rest T_{k-1} - T_{k-2}.
     // fuse_last: the rows of at most row_thresh entries of the LAST hop are gathered inside the projection (project_x3_gather_kernel); the
     // hop launch then covers the longer rows only, and the last hop tensor is neither written nor read for the others.
-    for (int64_t b = 0; b < qn; ++b)
+    for (int64_t b = 0; b < qn; ++b) {
+      if (mode == 1) {
+        const int64_t units = vec_rows ? n_c * (C / 4) : n_c * (int64_t)C;
+        if (vec_rows) hipLaunchKernelGGL((gather_rows_i32_kernel<4>), dim3(grid_1d(units)), dim3(kBlock), 0, st, x0 + b * n * C, rows, hop_ptr(0) + b * bs_c, n_c, C, (int64_t)C);
+        else hipLaunchKernelGGL((gather_rows_i32_kernel<1>), dim3(grid_1d(units)), dim3(kBlock), 0, st, x0 + b * n * C, rows, hop_ptr(0) + b * bs_c, n_c, C, (int64_t)C);
+        TGCN_CHECK_LAUNCH("compact_layer (pack the kept rows of x)");
+      }
       for (int k = 1; k < K; ++k) {
-        tgcn_dense X = {k == 1 ? const_cast<float*>(x0) + b * n * C : hop_ptr(k - 1) + b * bs_c, 0, C};
+        tgcn_dense X = {(mode == 0 && k == 1) ? const_cast<float*>(x0) + b * n * C : hop_ptr(k - 1) + b * bs_c, 0, C};
         tgcn_dense Y = {hop_ptr(k) + b * bs_c, 0, C};
-        rc = hop_impl(stream, k == 1 ? A_first : A_rest, S, 1, C, &X, nullptr, 1.f, 0.f, nullptr, 0.f, &Y, nullptr, part, part_bytes,
-                      (fuse_last && k == K - 1) ? 1 : 0);
+        if (mode == 1 && k >= 2) {
+          tgcn_dense Zd = {hop_ptr(k - 2) + b * bs_c, 0, C};
+          rc = hop_impl(stream, A_rest, S, 1, C, &X, &Zd, 2.f, -1.f, nullptr, 0.f, &Y, nullptr, part, part_bytes, 0);
+        } else {
+          rc = hop_impl(stream, (mode == 0 && k == 1) ? A_first : A_rest, S, 1, C, &X, nullptr, 1.f, 0.f, nullptr, 0.f, &Y, nullptr, part, part_bytes,
+                        (fuse_last && k == K - 1) ? 1 : 0);
+        }
         if (rc != TGCN_OK) return rc;
       }
+    }
     // projection of the pass's qn time steps in one launch per row class: the per-vertex bias is read once per pass
-    terms[0] = x0;
+    terms[0] = mode == 1 ? hop_ptr(0) : x0;
     for (int k = 1; k < K; ++k) terms[k] = hop_ptr(k);
     float* o = out + q0 * n * N;
-    if (compact_id && g_compact_proj.load() == 1) {
+    if (one_proj) {
       // ONE launch over all vertices in order: x, bias and out stream contiguously; terms 1..K-1 are read through the vertex ->
       // compact id map (empty vertices read the zero row): twice the tile work of the split form, every byte in whole DRAM pages
       uint32_t bits = kProjMapTermsOnly;
@@ -980,18 +1028,22 @@ int tgcn_cheb_forward_compact_f32(void* stream, const tgcn_csr* A_first, const t
       if (rc != TGCN_OK) return rc;
       continue;
     }
-    // vertices with stored entries: all K terms (x through the row map, hop tensors in compact rows)
+    // kept vertices: all K terms (mode 0: x through the row map, hop tensors in compact rows; mode 1: every term in compact rows)
     ProjGather gat;
     gat.A = (K == 2) ? A_first : A_rest;                                // the last hop's operand and its gather source (hop K-2, or x for K = 2)
     gat.X = (K == 2) ? x0 : hop_ptr(K - 2);
     gat.xbs = (K == 2) ? n * (int64_t)C : bs_c;
     gat.term = K - 1; gat.thresh = S->row_thresh;
-    rc = project_impl(stream, n_c, C, N, K, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, rows, 1u, (int32_t)qn, a_bs, n * (int64_t)N,
-                      0, nullptr, fuse_last ? &gat : nullptr);
+    rc = project_impl(stream, n_c, C, N, K, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, rows, mode == 1 ? 0u : 1u, (int32_t)qn, a_bs,
+                      n * (int64_t)N, 0, nullptr, fuse_last ? &gat : nullptr);
     if (rc != TGCN_OK) return rc;
-    // the others: P_k = 0 for k >= 1, so out = x W_0 + bias
+    // the others.  mode 0: P_k = 0 for k >= 1, so out = x W'_0 + bias.  mode 1: the left-out vertices are ISOLATED (no entries, never pointed at):
+    // T_k = x, 0, -x, 0, ... so out = x (W_0 - W_2 + W_4 - ...) + bias = x W_left + bias.
     if (n_empty > 0) {
-      rc = project_impl(stream, n_empty, C, N, 1, terms, ldas, W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, empty_rows, 1u, (int32_t)qn, a_bs, n * (int64_t)N);
+      const float* xt[1] = {x0};
+      const int64_t xbs[1] = {n * (int64_t)C};
+      rc = project_impl(stream, n_empty, C, N, 1, xt, ldas, (mode == 1 || W_left) ? W_left : W, bias, bias_kind, n, 1, 0, o, N, 0, 0, -1, empty_rows, 1u, (int32_t)qn,
+                        xbs, n * (int64_t)N);
       if (rc != TGCN_OK) return rc;
     }
   }
@@ -1112,6 +1164,13 @@ int tgcn_fold_weight_f32(void* stream, int32_t K, int64_t CN, const float* fold,
   if (K < 1 || K > 4096 || CN < 1 || !fold || !W || !out || W == out) TGCN_FAIL(TGCN_ERR_INVALID, "fold_weight: bad argument");
   hipLaunchKernelGGL(fold_weight_kernel, dim3(grid_1d(CN)), dim3(kBlock), 0, (hipStream_t)stream, fold, W, out, (int)K, CN, (int)transpose);
   TGCN_CHECK_LAUNCH("tgcn_fold_weight_f32");
+  return TGCN_OK;
+}
+
+int tgcn_weight_layout_f32(void* stream, int32_t K, int32_t C, int32_t N, const float* W, float* out, int32_t kind) {
+  if (K < 1 || C < 1 || N < 1 || !W || !out || W == out || kind < 0 || kind > 2) TGCN_FAIL(TGCN_ERR_INVALID, "weight_layout: bad argument");
+  hipLaunchKernelGGL(weight_layout_kernel, dim3(grid_1d((int64_t)K * C * N)), dim3(kBlock), 0, (hipStream_t)stream, W, out, (int)K, (int)C, (int)N, (int)kind);
+  TGCN_CHECK_LAUNCH("tgcn_weight_layout_f32");
   return TGCN_OK;
 }
 

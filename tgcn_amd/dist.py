@@ -177,6 +177,14 @@ class VertexShardedCheb:
             t = self._bufs[name] = torch.zeros(shape, dtype=torch.float32, device=self.device)
         return t
 
+    def _rows(self, src, idx, out=None):
+        """src[idx] for a (rows, C) tensor through the row-packing kernel (tgcn_pack_rows_f32; the injected stand-in in CPU rehearsals)"""
+        if out is None:
+            out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+        if idx.numel():
+            self.pack_fn(src, idx, out)
+        return out
+
     # ------------------------------------------------------------------ diagnostics
     def describe(self):
         """what this rank exchanges per hop and time step: enough to tell a slow link from a wrong partition in one record"""
@@ -250,7 +258,7 @@ class VertexShardedCheb:
         allg = self.exchange != "halo"
         bias_l = bias_local
         if bias_kind == 2 and bias_local is not None and not allg:
-            bias_l = bias_local.index_select(0, self.local_perm)
+            bias_l = self._rows(bias_local, self.local_perm)
         marks = [] if self.collect_stats else None
         self._mark(marks, "start")
         for t0 in range(0, q, depth):
@@ -266,7 +274,7 @@ class VertexShardedCheb:
             else:
                 exts = {s: [self._buf(("ext", s - t0, k), (1, self.n_ext, C)) for k in range(K)] for s in steps}
                 for s in steps:
-                    exts[s][0][0, : owned].copy_(x_local[s].index_select(0, self.local_perm))
+                    self._rows(x_local[s], self.local_perm, exts[s][0][0, : owned])
                 own = lambda s, k: exts[s][k][:, : owned]
             for k in range(1, K):
                 works = {}
@@ -294,7 +302,10 @@ class VertexShardedCheb:
             for s in steps:
                 o = self.project_fn([own(s, k).reshape(owned, C) for k in range(K)], W, bias_l, bias_kind, owned)
                 o = o.reshape(owned, N)
-                out[s] = o if allg else o.index_select(0, self.local_inv)
+                if allg:
+                    out[s] = o
+                else:
+                    self._rows(o, self.local_inv, out[s])
             self._mark(marks, "projection_ms")
         self._close_stats(marks)
         return out
@@ -310,11 +321,11 @@ class VertexShardedCheb:
         out = torch.empty((q, owned, N), dtype=torch.float32, device=x_local.device)
         bias_l = bias_local
         if halo and bias_kind == 2 and bias_local is not None:
-            bias_l = bias_local.index_select(0, self.local_perm)
+            bias_l = self._rows(bias_local, self.local_perm)
         marks = [] if self.collect_stats else None
         self._mark(marks, "start")
         for s in range(q):
-            xs = x_local[s].index_select(0, self.local_perm) if halo else x_local[s]
+            xs = self._rows(x_local[s], self.local_perm) if halo else x_local[s]
             terms = [xs.unsqueeze(0)]
             for k in range(1, K):
                 ext = torch.empty((1, self.n_ext, C), dtype=torch.float32, device=xs.device)
@@ -333,7 +344,10 @@ class VertexShardedCheb:
                 terms.append(y)
                 self._mark(marks, "hops_ms")
             o = self.project_fn([t.reshape(owned, C) for t in terms], W, bias_l, bias_kind, owned).reshape(owned, N)
-            out[s] = o.index_select(0, self.local_inv) if halo else o
+            if halo:
+                self._rows(o, self.local_inv, out[s])
+            else:
+                out[s] = o
             self._mark(marks, "projection_ms")
         self._close_stats(marks)
         return out

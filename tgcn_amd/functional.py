@@ -66,6 +66,53 @@ def _aligned16(C_row, *tensors):
     return ok
 
 
+def weight_layout(W_kcn, kind):
+    """Re-layouts of a (K, C, N) layer weight in libtgcn_hip.so (tgcn_weight_layout_f32): kind 0 -> (C, K*N) column blocks W_0 | ... | W_{K-1}
+    (project-first form); kind 1 -> (K, N, C), W_k^T (the input gradient as a layer on (L^T, g, W^T)); kind 2 -> (N, K*C) (G = g W^T for all
+    terms in one projection)."""
+    _lib.require_device(W_kcn)
+    K, Cc, N = W_kcn.shape
+    W = W_kcn.contiguous()
+    out = torch.empty({0: (Cc, K * N), 1: (K, N, Cc), 2: (N, K * Cc)}[kind], dtype=torch.float32, device=W.device)
+    with torch.cuda.device(W.device):
+        _lib.check(_lib.lib().tgcn_weight_layout_f32(_lib.stream_ptr(), K, Cc, N, _lib.ptr(W), _lib.ptr(out), kind))
+    return out
+
+
+class RowPermFn(torch.autograd.Function):
+    """out[b, i] = x[b, perm[i]] for a (nb, rows, C) tensor -- the relabelling a GraphOperand.reordered() operand needs on the way in (perm)
+    and out (inv_perm) -- as a differentiable op on tgcn_pack_rows_f32: the backward is the same kernel with the inverse permutation."""
+
+    @staticmethod
+    def forward(ctx, x3, perm, inv):
+        ctx.perm, ctx.inv = perm, inv
+        return _permute_rows(x3, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _permute_rows(g, ctx.inv), None, None
+
+
+def _permute_rows(x3, perm):
+    _lib.require_device(x3, perm)
+    x3 = x3.float().contiguous()
+    out = torch.empty_like(x3)
+    with torch.cuda.device(x3.device):
+        for b in range(x3.shape[0]):
+            pack_rows(x3[b], perm, out[b])
+    return out
+
+
+def relabel_rows(t, perm, inv, dim=1):
+    """t with its axis `dim` (the vertex axis) permuted: t.index_select(dim, perm), differentiable, through the library's row-packing kernel"""
+    sh = t.shape
+    lead = 1
+    for d in sh[:dim]:
+        lead *= d
+    t3 = t.reshape(lead, sh[dim], -1)
+    return RowPermFn.apply(t3, perm, inv).reshape(sh)
+
+
 # ----------------------------------------------------------------------------------------- single ops
 @_on_device
 def csr_hop(op, x, z=None, alpha=1.0, beta=0.0, want_p=False, out=None, p_out=None, z2=None, gamma=0.0):
@@ -178,7 +225,7 @@ def chebyshev_values_grad(op, x3, W_kcn, g):
         return dval
     T = cheb_stack(op, x3.contiguous(), K - 1, MODE_CHEBYSHEV) if K > 2 else x3.contiguous().unsqueeze(0)      # T_0 .. T_{K-2}
     g = g.contiguous()
-    Wcat = W_kcn.permute(2, 0, 1).reshape(1, N, K * Crow).contiguous()
+    Wcat = weight_layout(W_kcn, 2).view(1, N, K * Crow)
     Gall = cheb_project([g.reshape(q * n, N)], Wcat, None, BIAS_NONE, n).view(q, n, K * Crow)
     G = [Gall[:, :, k * Crow:(k + 1) * Crow] for k in range(K)]
     opT = op.transpose()
@@ -278,10 +325,10 @@ def cheb_time_windows(op, series, weight_khg, bias, bias_kind, mode=MODE_POWER):
     trained through."""
     _lib.require_device(series, weight_khg, bias)
     if op.perm is not None:        # reordered operand: its hops work in their own labels (differentiable index ops, as in cheb_layer)
-        series = series.index_select(1, op.perm)
+        series = relabel_rows(series, op.perm, op.inv_perm)
         if bias is not None and bias_kind == BIAS_VERTEX_CHANNEL:
-            bias = bias.reshape(op.n, -1).index_select(0, op.perm)
-        return ChebWindowsFn.apply(series, weight_khg, bias, op, mode, bias_kind).index_select(1, op.inv_perm)
+            bias = relabel_rows(bias.reshape(op.n, -1), op.perm, op.inv_perm, dim=0)
+        return relabel_rows(ChebWindowsFn.apply(series, weight_khg, bias, op, mode, bias_kind), op.inv_perm, op.perm)
     return ChebWindowsFn.apply(series, weight_khg, bias, op, mode, bias_kind)
 
 
@@ -344,10 +391,13 @@ def cheb_forward_raw(op, x3, Wt, bias, bias_kind, mode, K, layout=None, q_chunk=
 
 
 @_on_device
-def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
-    """Mode-0 forward on an operand with structurally empty rows (graph.CompactPlan) through tgcn_cheb_forward_compact_f32:
-    hop tensors only for the vertices that have entries.  x3: (q, n, C) contiguous; Wt: (K*C, N) folded."""
-    _lib.require_device(x3, Wt, bias)
+def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None, mode=MODE_POWER, W_left=None, keep=False):
+    """Layer forward on an operand with left-out vertices (graph.CompactPlan) through ONE call of tgcn_cheb_compact_layer_f32: hop tensors only
+    for the kept vertices, both recurrences.  x3: (q, n, C) contiguous; Wt: (K*C, N) in the working basis (folded for MODE_POWER); W_left:
+    (C, N) matrix of the left-out vertices (MODE_CHEBYSHEV: W_0 - W_2 + W_4 - ..., left_out_weight; MODE_POWER: None = W'_0).
+    keep=True: the hop tensors are written into one caller-owned buffer and returned as the layer's basis -- the list compact_terms gives
+    ([x3, P_1, ..] for MODE_POWER, [T_0, T_1, ..] for MODE_CHEBYSHEV; compact terms are (q, n_c + 1, C) with a zero last row) -> (out, terms)."""
+    _lib.require_device(x3, Wt, bias, W_left)
     L = _lib.lib()
     q, n, Crow = x3.shape
     N = Wt.shape[1]
@@ -372,14 +422,21 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None):
                 passes = -(-q // most)
                 q_chunk = plan.q_chunk_cache[key] = -(-q // passes)
     sched = plan.schedule_for(Crow, Crow % 4 == 0)
-    ws_bytes = L.tgcn_cheb_forward_compact_workspace_bytes(C.byref(sched.struct), K, q, plan.n_c, Crow, q_chunk)
+    kept = None
+    if keep:
+        nt = K if mode == MODE_CHEBYSHEV else K - 1
+        kept = torch.empty((nt, q, plan.n_c + 1, Crow), dtype=torch.float32, device=x3.device)
+    ws_bytes = L.tgcn_cheb_compact_layer_workspace_bytes(C.byref(sched.struct), mode, K, q, plan.n_c, Crow, q_chunk, 1 if keep else 0)
     ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
     out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
-    _lib.check(L.tgcn_cheb_forward_compact_f32(_lib.stream_ptr(), C.byref(plan.first.struct), C.byref(plan.rest.struct),
-                                               C.byref(sched.struct), K, q, n, Crow, N, _lib.ptr(x3), _lib.ptr(Wt), _lib.ptr(bias),
-                                               bias_kind, _lib.ptr(out), _lib.ptr(plan.rows), _lib.ptr(plan.empty), plan.n_empty,
-                                               _lib.ptr(plan.cid), q_chunk, _lib.ptr(ws), ws.numel()))
-    return out
+    _lib.check(L.tgcn_cheb_compact_layer_f32(_lib.stream_ptr(), C.byref(plan.first.struct), C.byref(plan.rest.struct), C.byref(sched.struct), mode, K, q, n,
+                                             Crow, N, _lib.ptr(x3), _lib.ptr(Wt), _lib.ptr(W_left), _lib.ptr(bias), bias_kind, _lib.ptr(out),
+                                             _lib.ptr(plan.rows), _lib.ptr(plan.empty), plan.n_empty, _lib.ptr(plan.cid), q_chunk, _lib.ptr(kept),
+                                             _lib.ptr(ws), ws.numel()))
+    if not keep:
+        return out
+    terms = ([x3] if mode == MODE_POWER else []) + [kept[i] for i in range(kept.shape[0])]
+    return out, terms
 
 
 COMPACT_LAYOUT1 = False           # compact hop tensors for the vertex-major layout too: built and tested, measured on cfg5n (TGCNCheb(L,1,64,5), q = 16 on the
@@ -411,11 +468,11 @@ def _compact_buffer(plan, q, C_row, device):
     return t
 
 
-def _gather_rows(src3, rows64, plan):
-    """src3[:, rows] into a compact buffer (index plumbing; one contiguous (n_c, C) block per sample)"""
-    out = _compact_buffer(plan, src3.shape[0], src3.shape[2], src3.device)
+def _gather_rows(src3, rows64, plan, out=None):
+    """src3[:, rows] into a compact buffer (tgcn_pack_rows_f32; one contiguous (n_c, C) block per sample)"""
+    out = _compact_buffer(plan, src3.shape[0], src3.shape[2], src3.device) if out is None else out
     for b in range(src3.shape[0]):
-        torch.index_select(src3[b], 0, rows64, out=out[b, : plan.n_c])
+        pack_rows(src3[b], rows64, out[b, : plan.n_c])
     return out
 
 
@@ -430,39 +487,56 @@ def _compact_hop(op, X, Y, plan, z=None, alpha=1.0, beta=0.0):
 
 @_on_device
 def compact_terms(plan, x3, K, mode):
-    """The K terms of the layer's basis with hop tensors for the plan's n_c kept vertices only.
+    """The K terms of the layer's basis with hop tensors for the plan's n_c kept vertices only (a backward without a kept basis recomputes them
+    here; the forward itself is one driver call, cheb_forward_compact).
     mode 0: [x3, P_1, ..., P_{K-1}], P_k = L^k x (monomials: the basis of the FOLDED weight); term 0 is x itself in the caller's labels.
-    mode 1: [T_0, ..., T_{K-1}] Chebyshev, every term compact (T_0 = x gathered to the kept rows).
-    Compact terms are (q, n_c + 1, C) buffers whose last row is zero."""
+    mode 1: [T_0, ..., T_{K-1}] Chebyshev, every term compact (T_0 = x packed to the kept rows).
+    Compact terms are views of ONE (T, q, n_c + 1, C) buffer whose last rows are zero."""
     q, n, Crow = x3.shape
-    dev = x3.device
+    nt = K if mode == MODE_CHEBYSHEV else K - 1
+    buf = torch.empty((max(nt, 1), q, plan.n_c + 1, Crow), dtype=torch.float32, device=x3.device)
+    buf[:, :, plan.n_c].zero_()
     if mode == MODE_POWER:
         terms = [x3]
         for k in range(1, K):
-            Y = _compact_buffer(plan, q, Crow, dev)
-            _compact_hop(plan.first if k == 1 else plan.rest, terms[k - 1], Y, plan)
-            terms.append(Y)
+            _compact_hop(plan.first if k == 1 else plan.rest, terms[k - 1], buf[k - 1], plan)
+            terms.append(buf[k - 1])
         return terms
-    rows64 = plan.rows.long()
-    terms = [_gather_rows(x3, rows64, plan)]
+    terms = [_gather_rows(x3, plan.rows64(), plan, out=buf[0])]
     for k in range(1, K):
-        Y = _compact_buffer(plan, q, Crow, dev)
         if k == 1:
-            _compact_hop(plan.rest, terms[0], Y, plan)
+            _compact_hop(plan.rest, terms[0], buf[1], plan)
         else:
-            _compact_hop(plan.rest, terms[k - 1], Y, plan, z=terms[k - 2], alpha=2.0, beta=-1.0)
-        terms.append(Y)
+            _compact_hop(plan.rest, terms[k - 1], buf[k], plan, z=terms[k - 2], alpha=2.0, beta=-1.0)
+        terms.append(buf[k])
     return terms
+
+
+_sign_cache = {}
+
+
+def _left_out_fold(K, device):
+    """(K, K) fold matrix whose column 0 holds the signs +1, 0, -1, 0, ... of T_k of an isolated vertex: tgcn_fold_weight_f32 with it puts
+    W_0 - W_2 + W_4 - ... into out[0]"""
+    key = (K, str(device))
+    with _fold_lock:
+        m = _sign_cache.get(key)
+        if m is None:
+            m = torch.zeros(K, K, dtype=torch.float32)
+            for k in range(0, K, 2):
+                m[k, 0] = 1.0 if k % 4 == 0 else -1.0
+            m = _sign_cache[key] = m.to(device)
+    return m
 
 
 def left_out_weight(W_kcn, mode):
     """(C, N) matrix of the vertices a plan leaves out: out[i] = x[i] @ this + bias.  mode 0 (W in the monomial basis): W'_0 -- every
-    P_k[i], k >= 1, is zero.  mode 1: W_0 - W_2 + W_4 - ... -- T_k[i] = x[i], 0, -x[i], 0, ... for an isolated vertex."""
+    P_k[i], k >= 1, is zero.  mode 1: W_0 - W_2 + W_4 - ... -- T_k[i] = x[i], 0, -x[i], 0, ... for an isolated vertex (the signed sum
+    runs in tgcn_fold_weight_f32)."""
+    W_kcn = W_kcn.contiguous()
     if mode == MODE_POWER:
-        return W_kcn[0].contiguous()
-    K = W_kcn.shape[0]
-    sign = torch.tensor([(1.0 if k % 4 == 0 else -1.0) if k % 2 == 0 else 0.0 for k in range(K)], dtype=W_kcn.dtype, device=W_kcn.device)
-    return (W_kcn * sign.view(K, 1, 1)).sum(0).contiguous()
+        return W_kcn[0]
+    return fold_weight(_left_out_fold(W_kcn.shape[0], W_kcn.device), W_kcn)[0]
 
 
 @_on_device
@@ -486,11 +560,10 @@ def project_mapped(terms, term_bs, W2d, bias, bias_kind, n_vertices, rowmap, map
 
 
 @_on_device
-def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, terms=None):
-    """Layer forward with compact hop tensors from primitive calls of the library (hops on the plan's operands, two row-mapped projections):
-    the form the training forward / backward and the Chebyshev-recurrence classes use (inference of the dense-L classes takes the one-call
-    driver tgcn_cheb_forward_compact_f32, same kernels).  Wt_kcn: (K, C, N) in the WORKING basis (folded for mode 0).
-    -> (out (q, n, N), terms)"""
+def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, keep=True):
+    """Layer forward with compact hop tensors that also hands back the basis (training forward, and the Chebyshev-recurrence classes): ONE
+    driver call (cheb_forward_compact -> tgcn_cheb_compact_layer_f32; round 4 issued the hops and the two row-mapped projections from here).
+    Wt_kcn: (K, C, N) in the WORKING basis (folded for mode 0).  -> (out (q, n, N), terms or None)"""
     _lib.require_device(x3, Wt_kcn, bias)
     q, n, Crow = x3.shape
     K, _, N = Wt_kcn.shape
@@ -499,9 +572,9 @@ def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, terms=None):
         x3 = x3.clone()
     b = bias.contiguous() if bias is not None else None
     if choose_layout(q, n, Crow) == 1:
-        # short per-sample rows: one long row per vertex for the gathers, (n, q*C) -- the hop tensors are (n_c + 1, q*C), the projections read
-        # them as (vertex, sample) rows of C floats and write the sample-major output through the row map (interleave = q)
-        assert terms is None
+        # short per-sample rows (COMPACT_LAYOUT1, off by default: slower on cfg5n): one long row per vertex for the gathers, (n, q*C) -- the hop
+        # tensors are (n_c + 1, q*C), the projections read them as (vertex, sample) rows of C floats and write the sample-major output through
+        # the row map (interleave = q); primitive calls of the library
         xt = relayout_qnc_to_nqc(x3).view(1, n, q * Crow)
         tt = compact_terms(plan, xt, K, mode)
         out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
@@ -510,17 +583,9 @@ def compact_forward(plan, x3, Wt_kcn, bias, bias_kind, mode, terms=None):
         if plan.n_empty:
             project_mapped([xt], [0], left_out_weight(Wt_kcn, mode), b, bias_kind, n, plan.empty, 1, q, out, interleave=q)
         return out, None
-    if terms is None:
-        terms = compact_terms(plan, x3, K, mode)
-    out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
-    cbs = (plan.n_c + 1) * Crow
-    if mode == MODE_POWER:        # term 0 = x through the row map, the others compact
-        project_mapped(terms, [n * Crow] + [cbs] * (K - 1), Wt_kcn.reshape(K * Crow, N).contiguous(), b, bias_kind, n, plan.rows, 1, q, out)
-    else:
-        project_mapped(terms, [cbs] * K, Wt_kcn.reshape(K * Crow, N).contiguous(), b, bias_kind, n, plan.rows, 0, q, out)
-    if plan.n_empty:
-        project_mapped([x3], [n * Crow], left_out_weight(Wt_kcn, mode), b, bias_kind, n, plan.empty, 1, q, out)
-    return out, terms
+    W_left = left_out_weight(Wt_kcn, mode) if (mode == MODE_CHEBYSHEV and plan.n_empty) else None
+    res = cheb_forward_compact(plan, x3, Wt_kcn.reshape(K * Crow, N).contiguous(), b, bias_kind, K, mode=mode, W_left=W_left, keep=keep)
+    return res if keep else (res, None)
 
 
 @_on_device
@@ -530,7 +595,7 @@ def compact_wgrad(plan, x3, terms, g, mode):
     q, n, Crow = x3.shape
     N = g.shape[2]
     K = len(terms)
-    g_c = _gather_rows(g, plan.rows.long(), plan)                             # (q, n_c + 1, N), zero last row
+    g_c = _gather_rows(g, plan.rows64(), plan)                               # (q, n_c + 1, N), zero last row
     gc2 = g_c.reshape(q * (plan.n_c + 1), N)
     S_all = cheb_wgrad([x3.reshape(q * n, Crow)], g.reshape(q * n, N))[0]     # x^T g over every vertex
     flat = lambda t: t.reshape(q * (plan.n_c + 1), Crow)
@@ -586,7 +651,7 @@ def cheb_stack(op, x3, K, mode, _operand_labels=False):
     true-recurrence stack for mode 1.  Materialising path: every hop writes its slice of the stack."""
     _lib.require_device(x3)
     if op.perm is not None and not _operand_labels:       # reordered operand: relabel on the way in and out (the shared operand is never touched)
-        return cheb_stack(op, x3.index_select(1, op.perm), K, mode, _operand_labels=True).index_select(2, op.inv_perm)
+        return relabel_rows(cheb_stack(op, relabel_rows(x3, op.perm, op.inv_perm), K, mode, _operand_labels=True), op.inv_perm, op.perm, dim=2)
     q, n, Crow = x3.shape
     st = torch.empty((K, q, n, Crow), dtype=torch.float32, device=x3.device)
     st[0].copy_(x3)
@@ -691,7 +756,7 @@ def cheb_forward_pf(op, x3, Wt_kcn, bias, bias_kind, mode):
     L = _lib.lib()
     q, n, Crow = x3.shape
     K, _, N = Wt_kcn.shape
-    Wcat = Wt_kcn.permute(1, 0, 2).reshape(Crow, K * N).contiguous()
+    Wcat = weight_layout(Wt_kcn, 0)
     sched = op.schedule_for(N, N % 4 == 0)
     ws_bytes = L.tgcn_cheb_forward_pf_workspace_bytes(C.byref(sched.struct), K, q, n, N)
     ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
@@ -726,16 +791,16 @@ def layer_forward(op, x3, W, fold, b, bias_kind, mode):
     if plan is not None and mode == MODE_POWER and choose_layout(x3.shape[0], x3.shape[1], Crow) == 0:   # many structurally empty rows: compact hop tensors, one call
         return cheb_forward_compact(plan, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, K)
     if plan is not None:                                   # the same for the Chebyshev recurrence (closed form for isolated vertices)
-        return compact_forward(plan, x3, Wt, b, bias_kind, mode)[0]
+        return compact_forward(plan, x3, Wt, b, bias_kind, mode, keep=False)[0]
     return cheb_forward_raw(op, x3, Wt.reshape(K * Crow, N).contiguous(), b, bias_kind, mode, K)
 
 
 @_on_device
 def relayout_qnc_to_nqc(x3):
-    """(q, n, C) -> (n, q, C) contiguous: the LDS-tiled transpose kernel for C <= 32, torch otherwise."""
+    """(q, n, C) -> (n, q, C) contiguous (tgcn_relayout_qnc_to_nqc_f32: LDS-tiled transpose for C <= 32, coalesced row copy beyond)."""
     q, n, Crow = x3.shape
-    if Crow > 32 or q == 1:
-        return x3.permute(1, 0, 2).contiguous()
+    if q == 1:
+        return x3.contiguous().view(n, 1, Crow)          # one sample: the same memory
     _lib.require_device(x3)
     out = torch.empty((n, q, Crow), dtype=torch.float32, device=x3.device)
     _lib.check(_lib.lib().tgcn_relayout_qnc_to_nqc_f32(_lib.stream_ptr(), _lib.ptr(x3.contiguous()), _lib.ptr(out), q, n, Crow))
@@ -842,9 +907,9 @@ def _to_operand_labels(op, x3, bias, bias_kind):
     bias into them (differentiable torch index ops: plumbing, no arithmetic)."""
     if op.perm is None:
         return x3, bias
-    x3 = x3.index_select(1, op.perm)
+    x3 = relabel_rows(x3, op.perm, op.inv_perm)
     if bias is not None and bias_kind == BIAS_VERTEX_CHANNEL:
-        bias = bias.reshape(op.n, -1).index_select(0, op.perm)
+        bias = relabel_rows(bias.reshape(op.n, -1), op.perm, op.inv_perm, dim=0)
     return x3, bias
 
 
@@ -854,7 +919,7 @@ def cheb_layer(op, x3, weight_kcn, bias, bias_kind, mode, values=None):
     x3, weight_kcn = _pad_rows(op, x3, weight_kcn, mode)
     x3, bias = _to_operand_labels(op, x3, bias, bias_kind)
     out = ChebLayerFn.apply(x3, weight_kcn, bias, op, mode, bias_kind, torch.is_grad_enabled(), values)
-    return out if op.perm is None else out.index_select(1, op.inv_perm)
+    return out if op.perm is None else relabel_rows(out, op.inv_perm, op.perm)
 
 
 @_on_device
@@ -900,19 +965,19 @@ def layer_backward(op, mode, fold, x3, W, g, bias_kind, bias_shape, needs, basis
             gW = fold_weight(fold, gW, transpose=True)
     if needs[0] and small_path_tile(op.transpose(), N, mode):
         # small graphs: dx = sum_j (L^T)^j g W_j^T is the one-launch forward kernel on (L^T, g, W^T)
-        gx = cheb_forward_small(op.transpose(), g, Wt.permute(0, 2, 1).contiguous(), None, None, BIAS_NONE, mode)
+        gx = cheb_forward_small(op.transpose(), g, weight_layout(Wt, 1), None, None, BIAS_NONE, mode)
     elif needs[0] and general and compact_plan_for(op.transpose(), mode, K, q, n, N, Crow) is not None:
         # dx = sum_k T_k(L^T) g W_k^T IS the layer on (L^T, g, W^T): with left-out vertices in L^T it runs on compact hop tensors too
         planT = compact_plan_for(op.transpose(), mode, K, q, n, N, Crow)
-        WtT = Wt.permute(0, 2, 1).contiguous()                       # (K, N, C)
+        WtT = weight_layout(Wt, 1)                                   # (K, N, C)
         if mode == MODE_POWER:
             gx = cheb_forward_compact(planT, g, WtT.reshape(K * N, Crow), None, BIAS_NONE, K)
         else:
-            gx = compact_forward(planT, g, WtT, None, BIAS_NONE, mode)[0]
+            gx = compact_forward(planT, g, WtT, None, BIAS_NONE, mode, keep=False)[0]
     elif needs[0]:
         opT = op.transpose()
         # G[m, k*C + c] = sum_n g[m, n] W[k, c, n]: one projection with the (N, K*C) transposed weight
-        Wcat = Wt.permute(2, 0, 1).reshape(1, N, K * Crow).contiguous()
+        Wcat = weight_layout(Wt, 2).view(1, N, K * Crow)
         Gall = cheb_project([g2d], Wcat, None, BIAS_NONE, n).view(q, n, K * Crow)
         G = [Gall[:, :, k * Crow:(k + 1) * Crow] for k in range(K)]        # strided views, rows contiguous
         if mode == MODE_POWER:                                       # Horner: b = G_j + L^T b

@@ -219,6 +219,13 @@ class CompactPlan:
     def schedule_for(self, C_row, aligned16=True):
         return self.rest.schedule_for(C_row, aligned16)
 
+    def rows64(self):
+        """`rows` as int64 (the row-packing kernel's index type), made once"""
+        r = getattr(self, "_rows64", None)
+        if r is None:
+            r = self._rows64 = self.rows.long()
+        return r
+
 
 class GraphOperand:
     """L-hat (n x n) in CSR with 8-byte packed {int32 col, float val} entries, on one device."""
