@@ -485,3 +485,34 @@ def test_wave_segment_schedule_shapes(lpr, monkeypatch):
         assert (slot[mine] < 0).all() == (deg[r] <= wave_len)
     assert s.nlong == int((deg > wave_len).sum())
     assert graph.Schedule(op.rowptr, n, 64, edges=op.edges).seg_mode == 0      # a whole wave per row chunk: nothing to fold
+
+
+def test_hub_first_reordering_warns_and_spreads_the_hot_block():
+    """a hub-first order is a pessimisation on power-law graphs (measured, profiles/r05_exp_reorder_degree.log), so
+    asking for one says so; the hot block of the order is bit-reversed (neighbours in popularity are not neighbours in the sweep)."""
+    import warnings
+    from tgcn_amd.graph import GraphOperand, _spread_hot_block
+    rng = np.random.default_rng(2)
+    n = 4096
+    row = np.minimum((rng.random(40000) ** 3 * n).astype(np.int64), n - 1)
+    col = rng.integers(0, n, 40000)
+    op = GraphOperand.from_coo(n, torch.as_tensor(row), torch.as_tensor(col), torch.ones(40000))
+    with pytest.warns(UserWarning, match="hub-first vertex order is measured"):
+        a = op.reordered("hub_first")
+    with pytest.warns(UserWarning, match="renamed 'hub_first'"):
+        b = op.reordered("degree")
+    with pytest.warns(UserWarning, match="hub-first"):
+        c = op.reordered("degree_sorted")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        op.reordered("rcm")
+    assert torch.equal(a.perm, b.perm) and torch.equal(torch.sort(a.perm)[0], torch.arange(n))
+    deg = (op.rowptr[1:] - op.rowptr[:-1]).long()
+    assert torch.equal(c.perm, torch.argsort(deg, descending=True, stable=True))
+    live = int((deg > 0).sum())
+    H = 1 << ((live // 8).bit_length() - 1)
+    assert 16 <= H < n and torch.equal(a.perm[H:], c.perm[H:]) and not torch.equal(a.perm[:H], c.perm[:H])
+    assert torch.equal(torch.sort(a.perm[:H])[0], torch.sort(c.perm[:H])[0])
+    assert torch.equal(_spread_hot_block(torch.arange(16), 64), torch.tensor([0, 4, 2, 6, 1, 5, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15]))
+    with pytest.raises(Exception, match="unknown order"):
+        op.reordered("random")

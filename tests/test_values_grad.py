@@ -109,3 +109,74 @@ def test_spmm_is_differentiable_in_value_and_matrix(fn, shape, gpu_device):
     assert rel_err(out.detach().cpu().numpy().reshape(ref.shape), ref.detach().cpu().numpy()) <= 1e-5
     assert rel_err(v.grad.cpu().numpy(), vd.grad.cpu().numpy()) <= GRAD_TOL
     assert rel_err(M.grad.cpu().numpy(), Md.grad.cpu().numpy()) <= GRAD_TOL
+
+
+@pytest.mark.parametrize("n,E,f,g,K,small", [(60, 400, 4, 5, 3, True), (3000, 30000, 16, 8, 4, False), (70000, 200000, 8, 8, 3, False)])
+def test_training_with_learnable_edge_weights_keeps_one_operand(n, E, f, g, K, small, gpu_device, monkeypatch):
+    """every optimizer step bumps edge_weight's version; the operand cache used to key on it -- a full edge normalise +
+    COO -> CSR sort + schedule per step and up to 16 stale operands (each with its lazily built transpose and compact plans) kept alive.  Now
+    the operand is cached by PATTERN and its packed values are refreshed in place.  Several SGD steps: the cache holds one operand + the
+    link map, the operand object (and its schedules, its transpose) are the same objects throughout, and every step's output and
+    gradients equal those of a FRESH module that has never seen another weight."""
+    import copy
+    import tgcn_amd
+    from tgcn_amd import functional as F, graph
+    if not small:
+        monkeypatch.setattr(F, "SMALL_PATH", False)
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 50000)           # the 70 k case: half of its vertices are isolated -> compact plans in play
+    rng = np.random.default_rng(n + K)
+    ei_np = _edges(n if n < 70000 else n // 2, E, rng)              # 70 k: edges among the first half only
+    ei = torch.as_tensor(ei_np).cuda()
+    w = torch.nn.Parameter(torch.as_tensor(rng.uniform(0.5, 1.5, E).astype(np.float32)).cuda())
+    torch.manual_seed(3)
+    layer = tgcn_amd.ChebConv(f, g, K).cuda()
+    opt = torch.optim.SGD([w] + list(layer.parameters()), lr=0.05)
+    x = torch.as_tensor(rng.standard_normal((2, n, f)).astype(np.float32)).cuda()
+    gout = torch.as_tensor(rng.standard_normal((2, n, g)).astype(np.float32)).cuda()
+    first_op = None
+    for step in range(5):
+        opt.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        out = layer(xin, ei, w)
+        (out - gout).square().mean().mul(50.0).backward()              # a bounded objective: the parameters stay finite over the steps
+        ops = [v[0] for k, v in layer._ops._d.items() if isinstance(v[0], graph.GraphOperand)]
+        assert len(ops) == 1 and len(layer._ops._d) <= 2, list(layer._ops._d)          # one operand + the (src, coef) links
+        first_op = first_op or ops[0]
+        assert ops[0] is first_op and ops[0]._transpose is not None                     # same object: schedules / transpose built once
+        # a fresh module with the current parameters and a weight tensor that was never seen before
+        fresh = copy.deepcopy(layer)
+        w2 = w.detach().clone().requires_grad_(True)
+        x2 = x.clone().requires_grad_(True)
+        out2 = fresh(x2, ei.clone(), w2)
+        (out2 - gout).square().mean().mul(50.0).backward()
+        assert rel_err(out.detach().cpu().numpy(), out2.detach().cpu().numpy()) <= 2e-6
+        for a, b in ((w.grad, w2.grad), (xin.grad, x2.grad), (layer.weight.grad, fresh.weight.grad)):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= GRAD_TOL
+        opt.step()
+    # a COMPUTED weight (new tensor every forward, as from a small network): still one operand
+    scale = torch.nn.Parameter(torch.ones((), device="cuda"))
+    for _ in range(3):
+        out = layer(x, ei, w.detach() * scale)
+        out.sum().backward()
+    assert len([v for v in layer._ops._d.values() if isinstance(v[0], graph.GraphOperand)]) == 1
+    assert scale.grad is not None and torch.isfinite(scale.grad)
+
+
+def test_spmm_with_a_learnable_value_keeps_one_operand(gpu_device):
+    import tgcn_amd
+    from tgcn_amd import nn as tnn, graph
+    rng = np.random.default_rng(9)
+    n, E = 500, 4000
+    idx = torch.as_tensor(rng.integers(0, n, (2, E))).cuda()
+    val = torch.nn.Parameter(torch.as_tensor(rng.standard_normal(E).astype(np.float32)).cuda())
+    m = torch.as_tensor(rng.standard_normal((3, n, 6)).astype(np.float32)).cuda()
+    before = len(tnn._spmm_ops._d)
+    opt = torch.optim.SGD([val], lr=0.1)
+    for _ in range(4):
+        opt.zero_grad()
+        out = tgcn_amd.spmm_batch_2(idx, val, n, m)
+        ref = torch.zeros(3, n, 6, dtype=torch.float64, device="cuda").index_add_(1, idx[0], m.double()[:, idx[1]] * val.detach().double().view(1, E, 1))
+        assert rel_err(out.detach().cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+        out.square().sum().backward()
+        opt.step()
+    assert len(tnn._spmm_ops._d) - before <= 2          # the operand and the entry order, however many steps

@@ -185,6 +185,28 @@ def _sched_build_library(self, rowptr, n, lanes_per_row, edges, n_cols):
 Schedule._build_library = _sched_build_library
 
 
+def _spread_hot_block(perm, n_live):
+    """Hub-first order without the hub pile-up: the first H = 2^floor(log2(n_live / 8)) positions of a degree-sorted order (the hot block: on the
+    10 M / 160 M R-MAT 524,288 vertices that take 84 % of the gathers) are visited in BIT-REVERSED order, the rest stays sorted.  A plain
+    degree-sorted order makes the column-ordered sweep of hop_kernel walk the columns in order of popularity, so that every workgroup in
+    flight asks for the same few hub lines at the same time (docs/EXPERIMENTS.md A.4: same L2 hit rate as random labels, 4x the L2 tag stalls,
+    +19 % fabric read latency, 3.96 vs 3.69 ms per launch); bit reversal keeps the hot rows together in one block (cache-resident) but makes
+    neighbours in popularity neither neighbours in memory nor in the sweep."""
+    if n_live < 16:
+        return perm
+    bits = (n_live // 8).bit_length() - 1
+    if bits < 1:
+        return perm
+    H = 1 << bits
+    p = torch.arange(H, device=perm.device, dtype=torch.int64)
+    r = torch.zeros_like(p)
+    for i in range(bits):
+        r |= ((p >> i) & 1) << (bits - 1 - i)
+    out = perm.clone()
+    out[:H] = perm[r]
+    return out
+
+
 class CompactPlan:
     """Operand with structurally empty rows (R-MAT: 5.27 M of 10 M vertices; the isolated fake vertices the reference's
     coarsening pads with, gcn/coarsening.py:167-217) prepared for tgcn_cheb_forward_compact_f32: hop tensors exist only for
@@ -301,22 +323,64 @@ class GraphOperand:
                 self._compact[kind] = plan
             return self._compact[kind]
 
+    def update_values(self, vals, _from_transpose=False):
+        """New VALUES on the same pattern, in place (vals: (nnz,) fp32 in this operand's CSR order): learnable edge weights change every
+        optimizer step while edge_index does not, and everything expensive -- the COO -> CSR sort, the schedules, the compact plans' row maps --
+        depends on the pattern only.  The packed entries, the dense copy, the compact plans' second entry array and the cached transpose (through
+        a once-computed entry map) are refreshed; device pointers do not move, so the ctypes structs stay valid."""
+        if self.nnz == 0:
+            return
+        vals = vals.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
+        assert vals.numel() == self.nnz
+        bits = vals.contiguous().view(torch.int32)
+        self.edges[: self.nnz, 1] = bits
+        if self.dense is not None:
+            counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), counts)
+            self.dense.zero_()
+            self.dense.index_put_((rows, self.edges[: self.nnz, 0].to(torch.int64)), vals, accumulate=True)
+        with self._lock:
+            plans = [pl for pl in (self._compact or {}).values() if pl is not None] if self._compact is not False else []
+            for pl in plans:
+                if pl.rest.edges.data_ptr() != self.edges.data_ptr():
+                    pl.rest.edges[: self.nnz, 1] = bits
+            T = self._transpose
+            if T is not None and not _from_transpose:
+                order = getattr(self, "_t_order", None)
+                if order is None:        # entry j of the transpose is entry order[j] of this operand: the builder's stable (row', col') = (col, row) sort
+                    row, col, _ = self.coo()
+                    order = self._t_order = torch.argsort(col * max(self.n, self.n_cols) + row, stable=True)
+                T.update_values(vals[order], _from_transpose=True)
+
     def __deepcopy__(self, memo):
         """An operand is immutable once built (device arrays + ctypes structs that point into them): copies of a module share it."""
         return self
 
     # ------------------------------------------------------------------ vertex reordering (SURVEY.md 8f-4)
     def reordered(self, kind):
-        """The same operator with its vertices relabelled for locality -- P L P^T plus the permutation, which the layer
-        functions apply to x / bias on the way in and to the result on the way out (functional.cheb_layer), so callers keep
-        their own labels.  "degree": decreasing number of stored entries (hubs first); "rcm": reverse Cuthill-McKee of the
-        symmetrised pattern (scipy, on the host, one-off) -- the bandwidth-reducing order the reference's coarsened graphs
-        get from their construction (gcn/coarsening.py:167-217 orders vertices by cluster).  Square operands only."""
+        """The same operator with its vertices relabelled -- P L P^T plus the permutation, which the layer functions apply to x / bias on
+        the way in and to the result on the way out (functional.cheb_layer), so callers keep their own labels.  Square operands only.
+          "rcm"        reverse Cuthill-McKee of the symmetrised pattern (scipy, on the host, one-off): the bandwidth-reducing order the
+                       reference's coarsened graphs get from their construction (gcn/coarsening.py:167-217 orders vertices by cluster).
+                       THE order to use for graphs that have locality under some labelling (meshes, banded, k-NN grids with scrambled ids).
+          "hub_first"  decreasing number of stored entries, the hot block visited in bit-reversed order (_spread_hot_block).  NOT a speed-up on
+                       graphs without locality: on the 10 M / 160 M R-MAT the hop takes 3.99 ms per launch against 3.73 ms with the caller's own
+                       (random) labels -- hop_kernel's column-ordered sweep already has the hub locality, and ANY hub-first order makes every
+                       workgroup in flight ask for the same hot block at the same time (profiles/r05_exp_reorder_degree.log; plain degree
+                       order: 4.18 ms; docs/EXPERIMENTS.md A.4).  Kept for experiments; warns.  ("degree": old name, same thing, warns too.)
+          "degree_sorted"  plain decreasing-degree order (round 1-4's "degree"): the slowest of the three on power-law graphs; warns."""
         assert self.n == self.n_cols, "reordered(): square operands only"
         row, col, val = self.coo()
-        if kind == "degree":
+        if kind in ("hub_first", "degree", "degree_sorted"):
+            import warnings
+            warnings.warn("GraphOperand.reordered(%r): a hub-first vertex order is measured 7-12 %% SLOWER than the caller's own labels on power-law graphs "
+                          "without locality (R-MAT 10 M / 160 M: 3.99 / 4.18 ms per hop launch against 3.73 ms; profiles/r05_exp_reorder_degree.log) -- "
+                          "use reordered('rcm') for graphs that have locality, or no reordering%s"
+                          % (kind, "; 'degree' was renamed 'hub_first'" if kind == "degree" else ""), stacklevel=2)
             deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
             perm = torch.argsort(deg, descending=True, stable=True)
+            if kind != "degree_sorted":
+                perm = _spread_hot_block(perm, int((deg > 0).sum().item()))
         elif kind == "rcm":
             import scipy.sparse as sp
             from scipy.sparse.csgraph import reverse_cuthill_mckee
@@ -324,7 +388,7 @@ class GraphOperand:
             pat = sp.coo_matrix((torch.ones(r.shape[0]).numpy(), (r, c)), shape=(self.n, self.n)).tocsr()
             perm = torch.as_tensor(reverse_cuthill_mckee((pat + pat.T).tocsr(), symmetric_mode=True).astype("int64"), device=self.device)
         else:
-            raise _lib.TgcnError("reordered(): unknown order %r (degree | rcm)" % (kind,))
+            raise _lib.TgcnError("reordered(): unknown order %r (rcm | hub_first | degree_sorted)" % (kind,))
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(self.n, device=self.device)
         op = GraphOperand.from_coo(self.n, inv[row], inv[col], val, self.device)

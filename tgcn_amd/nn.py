@@ -219,12 +219,44 @@ class GCNCheb(_DenseLBase):
 _spmm_ops = _OperandCache()
 
 
+def _stamp(t):
+    return (t.data_ptr(), t._version)
+
+
+def _refresh_values(op, stamp, make_vals):
+    """A LEARNABLE weight changes every optimizer step (and a computed one is a new tensor every forward) while the pattern stays: the operand is
+    cached by pattern and only its packed values are refreshed in place (GraphOperand.update_values) -- a cache keyed on the weight's version would
+    rebuild CSR, schedule and transpose per step and keep up to 16 stale operands alive."""
+    if getattr(op, "_packed_stamp", None) != stamp:
+        with op._lock:
+            if getattr(op, "_packed_stamp", None) != stamp:
+                op.update_values(make_vals())
+                op._packed_stamp = stamp
+    return op
+
+
 def _coo_operand(index, value, m, device, n_cols=None):
     """m x n_cols operand: the reference's gather / scatter_add form takes any number of source rows (gcn.py:296-308)."""
     n_cols = int(m if n_cols is None else n_cols)
+    if value.requires_grad:          # learnable values: one operand per PATTERN, values refreshed in place
+        key = ("learnable", _tensor_key(index), int(m), n_cols, str(device))
+        first = []
+        op = _spmm_ops.get(key, lambda: (first.append(1), GraphOperand.from_coo(int(m), index[0], index[1], value.detach(), device, n_cols=n_cols))[1],
+                           sources=(index,))
+        if first:
+            op._packed_stamp = _stamp(value)
+            return op
+        return _refresh_values(op, _stamp(value), lambda: value.detach().to(device=op.device, dtype=torch.float32).reshape(-1)[_coo_order(index, op)])
     key = (_tensor_key(index), _tensor_key(value), int(m), n_cols, str(device))
     return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value.detach(), device, n_cols=n_cols),
-                         sources=(index, value))
+                         sources=(index, value.detach()))      # the detached alias shares storage and version counter: the address cannot be reused, no graph is kept
+
+
+def _coo_order(index, op):
+    """entry order of GraphOperand.from_coo: sorted by (row, col), duplicates in their given order (tests/test_device_build.py pins both builders to it)"""
+    key = ("order", _tensor_key(index), op.n, op.n_cols, str(op.device))
+    return _spmm_ops.get(key, lambda: torch.argsort(index[0].to(op.device).long() * max(op.n, op.n_cols) + index[1].to(op.device).long(), stable=True),
+                         sources=(index,))
 
 
 def _coo_values(index, value, op):
@@ -232,10 +264,7 @@ def _coo_values(index, value, op):
     duplicates in their given order -- the order GraphOperand.from_coo packs (tests/test_device_build.py pins the two builders to it)."""
     if value is None or not value.requires_grad:
         return None
-    key = ("order", _tensor_key(index), op.n, op.n_cols, str(op.device))
-    order = _spmm_ops.get(key, lambda: torch.argsort(index[0].to(op.device).long() * max(op.n, op.n_cols) + index[1].to(op.device).long(), stable=True),
-                          sources=(index,))
-    return value.to(device=op.device, dtype=torch.float32).reshape(-1)[order]
+    return value.to(device=op.device, dtype=torch.float32).reshape(-1)[_coo_order(index, op)]
 
 
 def _spmm3(op, x3, values):
@@ -274,19 +303,24 @@ class _EdgeBase(torch.nn.Module):
         n = x.size(1)
         if edge_weight is not None:
             assert edge_weight.reshape(-1).size(0) == edge_index.size(1)
+        w = None if edge_weight is None else edge_weight.detach()        # shares storage and version counter; keeps no autograd graph alive
+        if edge_weight is not None and edge_weight.requires_grad:
+            # learnable weights: ONE operand per edge_index; the values lap_e = coef_e * w_e are refreshed in place when the weight has changed
+            key = ("learnable", _tensor_key(edge_index), n, str(x.device))
+            first = []
+            op = self._ops.get(key, lambda: (first.append(1), GraphOperand.from_edge_index(edge_index, w, n, x.device))[1], sources=(edge_index,))
+
+            def vals():
+                src, coef = self._links(edge_index, n, x.device)
+                return coef * w.to(device=x.device, dtype=torch.float32).reshape(-1)[src]
+            # (the first build's values are re-packed by the same formula as every later refresh, so that equal weights give bit-equal
+            # operands whatever the history of the module: the builder rounds -d^-1/2 w d^-1/2 in another order)
+            return _refresh_values(op, _stamp(edge_weight), vals)
         key = (_tensor_key(edge_index), _tensor_key(edge_weight), n, str(x.device))
-        w = None if edge_weight is None else edge_weight.detach()
-        return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, w, n, x.device),
-                             sources=(edge_index, edge_weight))
+        return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, w, n, x.device), sources=(edge_index, w))
 
-    def _values(self, x, edge_index, edge_weight, op):
-        """The operand's values in CSR order as a function of a LEARNABLE edge_weight (None otherwise): lap_e = -deg^-1/2[row] w_e deg^-1/2[col]
-        with the unweighted source degree (gcn.py:408-413), i.e. a constant coefficient per kept edge times its weight -- differentiable index
-        plumbing; the arithmetic of the gradient itself is F.chebyshev_values_grad."""
-        if edge_weight is None or not edge_weight.requires_grad:
-            return None
-        n, dev = x.size(1), x.device
-
+    def _links(self, edge_index, n, dev):
+        """(source edge of every stored entry, its constant coefficient -deg^-1/2[row] deg^-1/2[col]) in the operand's CSR order, once per edge_index"""
         def links():
             row, col = edge_index[0].to(dev).long(), edge_index[1].to(dev).long()
             ids = (row != col).nonzero().flatten()
@@ -295,7 +329,16 @@ class _EdgeBase(torch.nn.Module):
             dis = torch.bincount(r, minlength=n).to(torch.float32).pow(-0.5)
             dis[torch.isinf(dis)] = 0
             return ids[order], (-(dis[r] * dis[c]))[order]
-        src, coef = self._ops.get(("links", _tensor_key(edge_index), n, str(dev)), links, sources=(edge_index,))
+        return self._ops.get(("links", _tensor_key(edge_index), n, str(dev)), links, sources=(edge_index,))
+
+    def _values(self, x, edge_index, edge_weight, op):
+        """The operand's values in CSR order as a function of a LEARNABLE edge_weight (None otherwise): lap_e = -deg^-1/2[row] w_e deg^-1/2[col]
+        with the unweighted source degree (gcn.py:408-413), i.e. a constant coefficient per kept edge times its weight -- differentiable index
+        plumbing; the arithmetic of the gradient itself is F.chebyshev_values_grad."""
+        if edge_weight is None or not edge_weight.requires_grad:
+            return None
+        n, dev = x.size(1), x.device
+        src, coef = self._links(edge_index, n, dev)
         assert src.numel() == op.nnz
         return coef * edge_weight.to(device=dev, dtype=torch.float32).reshape(-1)[src]
 

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     ap.add_argument("--cold-last", type=int, default=None, help="reorder the entries inside every row: entries whose column is among the RANK most referenced "
                     "columns first (in column order), the others behind them (in column order) -- a gather instruction then carries lines of one latency class")
+    ap.add_argument("--reorder", default=None, help="GraphOperand.reordered(KIND) before anything else (degree | degree_sorted | rcm)")
     ap.add_argument("--cold-nt", action="store_true", help="with --cold-last: variant 5 runs on a copy of the entries whose COLD columns carry bit 31 "
                     "(hop_kernel gathers them with the non-temporal hint); every other variant runs on the plain entries")
     args = ap.parse_args()
@@ -77,6 +78,9 @@ def main():
         print("kept %d entries (%s rows)" % (row.numel(), args.only), flush=True)
     op = graph.GraphOperand.from_coo(args.n, row, col, val, dev)
     del row, col, val
+    if args.reorder:
+        op = op.reordered(args.reorder)
+        print("reordered(%r)" % args.reorder, flush=True)
     if args.compact:
         plan = op.compact_plan()
         print("compact: %d rows with entries, %d empty" % (plan.n_c, plan.n_empty), flush=True)
