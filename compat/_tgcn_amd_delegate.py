@@ -71,7 +71,12 @@ def install(module_globals, package, name, native):
     def __getattr__(attr):
         if attr.startswith("__") and attr.endswith("__"):
             raise AttributeError("module %r has no attribute %r" % (qual, attr))
-        ref = load_reference_module(package, name)
+        try:
+            ref = load_reference_module(package, name)
+        except ReferenceNotFound as e:
+            # a MISS for attribute probes -- hasattr(), getattr(mod, name, None), inspect / pytest / pickle.whichmodule scanning sys.modules -- with
+            # the cause in the message; `from gcn.graph import grid` turns it into the ImportError a missing name is
+            raise AttributeError(str(e)) from e
         try:
             return getattr(ref, attr)
         except AttributeError:

@@ -18,18 +18,20 @@ def _host_csr(op):
     return op.rowptr.cpu().numpy(), col.to(torch.int32).cpu().numpy(), val.cpu().numpy()
 
 
-def _check(layer, op, x, kind, q_check=None):
-    """layer(x) against the C restatement on the first q_check samples (reference basis weight, unfolded recursion)"""
+def _check(layer, op, x, kind, q_check=None, samples=None):
+    """layer(x) against the C restatement on the first q_check samples, or on the listed `samples` (reference basis weight, unfolded recursion)"""
     from oracle import c_port
     with torch.no_grad():
         out = layer(x)
-    q = x.shape[0] if q_check is None else q_check
+    sel = list(range(x.shape[0] if q_check is None else q_check)) if samples is None else list(samples)
     rowptr, col, val = _host_csr(op)
     K, g = layer.weight.shape[0], layer.weight.shape[-1]
     W = layer.weight.detach().reshape(K, -1, g).cpu().numpy()
     b = layer.bias.detach().reshape(-1).cpu().numpy()
-    ref = c_port.forward(0, rowptr, col, val, x[:q].reshape(q, op.n, -1).cpu().numpy(), W, b, kind)
-    assert rel_err(out[:q].cpu().numpy(), ref) <= TOL
+    xs = np.stack([x[i].reshape(op.n, -1).cpu().numpy() for i in sel])
+    ref = c_port.forward(0, rowptr, col, val, xs, W, b, kind)
+    got = np.stack([out[i].cpu().numpy() for i in sel])
+    assert rel_err(got, ref) <= TOL
     return out
 
 
@@ -124,9 +126,12 @@ def test_cfg5_reduced_rmat_tgcncheb(labeling, gpu_device):
     _check(layer, op, x, 2, q_check=2)
 
 
-def test_cfg5_full_size_one_time_step(gpu_device):
-    """configs[4] AT FULL SIZE -- the workload BENCH times: R-MAT 10 M vertices / 160 M entries (random labels), TGCNCheb(L, 64, 64, K=5)
-    -- one of its 16 time steps through the module, against oracle/cheb_ref.c (about 12 s on the box's host cores).  Asserts that it is
+@pytest.mark.parametrize("labeling", ["random", "degree"])
+def test_cfg5_full_size_one_time_step(labeling, gpu_device):
+    """configs[4] AT FULL SIZE -- the workload BENCH times: R-MAT 10 M vertices / 160 M entries, both labelings SURVEY 8(d) names (random =
+    the headline, degree-sorted = the "friendly" one), TGCNCheb(L, 64, 64, K=5) -- TWO of its 16 time steps through the module in one call,
+    the SECOND one (it sits behind the first's 640 M floats of x and out, and shares the pass with it: time steps per pass 2) against
+    oracle/cheb_ref.c (about 12 s on the box's host cores).  Asserts that it is
     the compacted path (5.27 M structurally empty rows -> compact hop tensors, row-mapped projections) with hop outputs beyond the
     Infinity Cache, i.e. the streaming form of hop_kernel with whole-row wave segments, lane-group segments and the fix-up: what
     bench.py's own check covers, under pytest.  (> 2^31-element offsets: tests/test_compact_wave.py::test_offsets_beyond_2_31_elements.)"""
@@ -134,7 +139,7 @@ def test_cfg5_full_size_one_time_step(gpu_device):
     from tgcn_amd import functional as F
     from tools import synth
     n, nnz = 10_000_000, 160_000_000
-    _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling="random", device=gpu_device)
+    _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling=labeling, device=gpu_device)
     op = tgcn_amd.GraphOperand.from_coo(n, row, col, val, gpu_device)
     del row, col, val
     assert op.nnz == nnz
@@ -147,12 +152,12 @@ def test_cfg5_full_size_one_time_step(gpu_device):
     torch.manual_seed(1)
     layer = tgcn_amd.TGCNCheb(op, 64, 64, 5).cuda()
     g = torch.Generator(device="cuda").manual_seed(0)
-    x = torch.randn((1, n, 64), device="cuda", generator=g)
+    x = torch.randn((2, n, 64), device="cuda", generator=g)
     calls = []
     real = F.cheb_forward_compact
     F.cheb_forward_compact = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     try:
-        _check(layer, op, x, 2)
+        _check(layer, op, x, 2, samples=[1])
     finally:
         F.cheb_forward_compact = real
     assert calls, "the module forward did not take the compacted driver"

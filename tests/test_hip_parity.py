@@ -937,3 +937,36 @@ def test_hop_scheduling_switches_keep_the_result(key, value, gpu_device):
         assert torch.equal(F.csr_hop(op, x), base)
     finally:
         _lib.check(_lib.lib().tgcn_set_tuning(key.encode(), {"hop_xcd_remap": 1, "hop_lds_pad": 0, "hop_seg_remap": 0, "hop_mix": 0, "hop_stream": 1}[key]))
+
+
+@pytest.mark.parametrize("variant", [0, 3, 4])
+def test_bf16x3_margin_at_k25_with_growing_terms(variant, gpu_device):
+    """the MARGIN of the bf16x3 projection, pinned where it is thinnest -- K = 25 of the dense-L classes' recursion
+    (Xt[k] = 2 L^k x - Xt[k-2]: the folded weights W'_j = sum_k c[k, j] W_k carry coefficients of both signs up to 2 that cancel in the
+    sum over the 25 monomial terms), 8,281 vertices x 2 samples = 16,562 rows (>= 8192: the shipped choice IS the bf16x3 kernel), 64 -> 64
+    channels.  Against the float64 evaluation of the reference's own unfolded recursion: <= 5e-6, half the 1e-5 bar (variant 4, exact
+    fp32 MFMA, for comparison under the same bound)."""
+    import tgcn_amd
+    from tgcn_amd import _lib
+    from tools import synth
+    n, row, col, val = synth.sheet_mesh(91)
+    assert n >= 8192
+    op = tgcn_amd.GraphOperand.from_coo(n, row, col, val)
+    torch.manual_seed(5)
+    layer = tgcn_amd.GCNCheb(op, 64, 64, 25).cuda()
+    rng = np.random.default_rng(25)
+    x = rng.standard_normal((2, n, 64)).astype(np.float32)
+    L = op.to_scipy().astype(np.float64)
+    W = layer.weight.detach().double().cpu().numpy()
+    Xt = [x.astype(np.float64)]
+    P = Xt[0]
+    for k in range(1, 25):
+        P = np.stack([L @ P[b] for b in range(2)])
+        Xt.append(P if k == 1 else 2 * P - Xt[k - 2])
+    ref = sum(Xt[k] @ W[k] for k in range(25)) + layer.bias.detach().double().cpu().numpy()
+    growth = max(np.abs(t).max() for t in Xt) / np.abs(Xt[0]).max()
+    _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", variant))
+    with torch.no_grad():
+        out = layer(_dev(x))
+    err = rel_err(out.cpu().numpy(), ref)
+    assert err <= 5e-6, (variant, err, growth)

@@ -318,15 +318,28 @@ print("ok")
 
 
 def test_compat_gcn_graph_without_a_reference_checkout_says_so():
-    """Only chebyshev is native; asking for a delegated name without a checkout behind compat/ is an ImportError naming the cause."""
+    """Only chebyshev is native; asking for a delegated name without a checkout behind compat/ is an AttributeError naming the cause (so that
+    attribute probes -- hasattr, getattr with a default, pickle.whichmodule -- see a miss), and an ImportError for `from gcn.graph import name`."""
     code = """
 import gcn.graph as graph
 assert callable(graph.chebyshev)
+assert not hasattr(graph, "grid") and getattr(graph, "rescale_L", None) is None
 try:
     graph.grid(4)
-except ImportError as e:
+except AttributeError as e:
     assert "checkout" in str(e) and "gcn/graph.py" in str(e), str(e)
-    print("ok")
+    assert type(e.__cause__).__name__ == "ReferenceNotFound"
+else:
+    raise SystemExit("no error")
+try:
+    from gcn.graph import laplacian
+except ImportError as e:
+    assert "laplacian" in str(e)
+else:
+    raise SystemExit("no import error")
+import pickle, sys
+assert pickle.whichmodule(len, "len") == "builtins"        # scans sys.modules with getattr(module, name, None): must not blow up on the shim
+print("ok")
 """
     r = _run_with_path(code, os.path.join(ROOT, "compat"), ROOT)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

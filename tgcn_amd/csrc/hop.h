@@ -29,6 +29,7 @@ struct HopParams {
   int32_t mix_period;            // kernel: > 1 one row block every mix_period block ids, < 0 segment blocks first, 0 / 1 row blocks first (host: the request, see launch_hop)
   int32_t stream_out;            // the output tensor is larger than the Infinity Cache: entries, results and partial rows with non-temporal hints
   int32_t seg_mode, seg_remap;   // seg_mode 1: one WAVE per segment (tgcn_csr_sched.seg_mode); seg_remap: XCD-contiguous segment ranges
+  int32_t long_rows_only;        // host only: the launch covers the rows above row_thresh only (fused last hop) -- names the profile record
 };
 
 template <int VEC>
@@ -457,7 +458,7 @@ template <int VEC>
 int launch_hop_vec(hipStream_t st, const HopParams& p, int lpr, dim3 grid, dim3 fix_grid) {
 #define TGCN_HOP_CASE(L)                                                                    \
   case L: {                                                                                 \
-    { ProfScope ps(p.nblk == 0 ? TGCN_PROF_HOP_LONG : TGCN_PROF_HOP, st);                   \
+    { ProfScope ps(p.long_rows_only ? TGCN_PROF_HOP_LONG : TGCN_PROF_HOP, st);              \
       if (!(VEC == 4 && g_hop_variant.load() != 0 && launch_hop_variant(L, st, p, grid))) { \
         /* interleave rows only when the grid still fills the chip afterwards */            \
         if (HopRows<L>::value > 1 && (int64_t)p.nblk * grid.y >= 4096)                       \

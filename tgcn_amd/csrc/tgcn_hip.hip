@@ -180,6 +180,7 @@ static int hop_impl(void* stream, const tgcn_csr* A, const tgcn_csr_sched* S, in
     if (S->nseg == 0) return TGCN_OK;       // no row above the threshold: nothing to do
     p.nblk = 0;                             // no row blocks: every workgroup of the launch is a segment block
     p.mix_period = 0;
+    p.long_rows_only = 1;                   // (a FULL hop on a schedule without row blocks is still a TGCN_PROF_HOP record: ADVICE r04)
   }
   const int gpb = kBlock / g.lpr;
   const int seg_blocks = (S->nseg + gpb - 1) / gpb;

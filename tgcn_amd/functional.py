@@ -213,28 +213,35 @@ class SpmmFn(torch.autograd.Function):
 
 
 @_on_device
-def chebyshev_values_grad(op, x3, W_kcn, g):
+def chebyshev_values_grad(op, x3, W_kcn, g, basis=None):
     """d loss / d values (CSR order) of the true-recurrence layer out = sum_k T_k W_k, T_1 = L x, T_k = 2 L T_{k-1} - T_{k-2} (ChebConv /
     ChebTimeConv: lap_e = -deg^-1/2[row] w_e deg^-1/2[col] is differentiable in w_e in the reference, tgcn/nn/gcn.py:413,510).
     With G_k = g W_k^T and the Clenshaw adjoints b_{K-1} = G_{K-1}, b_k = G_k + 2 L^T b_{k+1} - b_{k+2}:
-        dL = b_1 T_0^T + 2 sum_{k>=2} b_k T_{k-1}^T   sampled on the stored pattern (csr_sddmm).  Hops, projection and SDDMM in libtgcn_hip.so."""
+        dL = b_1 T_0^T + 2 sum_{k>=2} b_k T_{k-1}^T   sampled on the stored pattern (csr_sddmm).  Hops, projection and SDDMM in libtgcn_hip.so.
+    basis: the (q, n, C) terms T_0 .. T_{K-1} when the forward kept them (ChebLayerFn: forward_keeping_basis) -- otherwise T_0 .. T_{K-2} are
+    recomputed here.  Every adjoint is consumed by its sampled product as soon as it exists and only the two the recurrence still needs stay
+    alive (the K-1 adjoints used to be held until the SDDMM loop)."""
     K, Crow, N = W_kcn.shape
     q, n, _ = x3.shape
     dval = torch.zeros(max(op.nnz, 1), dtype=torch.float32, device=x3.device)[: op.nnz]
     if K < 2 or op.nnz == 0:
         return dval
-    T = cheb_stack(op, x3.contiguous(), K - 1, MODE_CHEBYSHEV) if K > 2 else x3.contiguous().unsqueeze(0)      # T_0 .. T_{K-2}
+    if basis is not None:
+        T = basis
+    else:
+        T = cheb_stack(op, x3.contiguous(), K - 1, MODE_CHEBYSHEV) if K > 2 else x3.contiguous().unsqueeze(0)      # T_0 .. T_{K-2}
     g = g.contiguous()
     Wcat = weight_layout(W_kcn, 2).view(1, N, K * Crow)
     Gall = cheb_project([g.reshape(q * n, N)], Wcat, None, BIAS_NONE, n).view(q, n, K * Crow)
-    G = [Gall[:, :, k * Crow:(k + 1) * Crow] for k in range(K)]
+    G = lambda k: Gall[:, :, k * Crow:(k + 1) * Crow]
     opT = op.transpose()
-    b = {K - 1: G[K - 1]}
-    for k in range(K - 2, 0, -1):
-        b[k] = csr_hop(opT, b[k + 1], z=b.get(k + 2), alpha=2.0, beta=-1.0, z2=G[k], gamma=1.0)
-    csr_sddmm(op, b[1], T[0], alpha=1.0, out=dval, accumulate=False)
-    for k in range(2, K):
-        csr_sddmm(op, b[k], T[k - 1], alpha=2.0, out=dval, accumulate=True)
+    b1, b2 = G(K - 1), None                     # b_k, b_{k+1} as the loop walks k = K-1 .. 1
+    first = True
+    for k in range(K - 1, 0, -1):
+        if k < K - 1:
+            b1, b2 = csr_hop(opT, b1, z=b2, alpha=2.0, beta=-1.0, z2=G(k), gamma=1.0), b1
+        csr_sddmm(op, b1, T[k - 1], alpha=1.0 if k == 1 else 2.0, out=dval, accumulate=not first)
+        first = False
     return dval
 
 
@@ -876,8 +883,15 @@ class ChebLayerFn(torch.autograd.Function):
         x3, W = ctx.saved_tensors
         gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad,
                                     basis=ctx.basis)
+        values_basis = ctx.basis if (isinstance(ctx.basis, tuple) and len(ctx.basis) == 2 and ctx.mode == MODE_CHEBYSHEV) else None
         ctx.basis = None
-        gv = chebyshev_values_grad(ctx.op, x3, W, g) if (len(ctx.needs_input_grad) > 7 and ctx.needs_input_grad[7]) else None
+        gv = None
+        if len(ctx.needs_input_grad) > 7 and ctx.needs_input_grad[7]:
+            kept = None
+            if values_basis is not None and not values_basis[1]:             # hop tensors kept by the forward in (sample, vertex) row order: T_0 .. T_{K-1}
+                q, n, Crow = x3.shape
+                kept = [r.view(q, n, Crow) for r in values_basis[0]]
+            gv = chebyshev_values_grad(ctx.op, x3, W, g, basis=kept)
         return gx, gW, gb, None, None, None, None, gv
 
 
