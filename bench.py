@@ -742,7 +742,8 @@ def main():
                                 arithmetic="f32 (bf16x3 projection: fp32 operands split into three bf16 terms on the matrix pipe)" if x3_proj else "f32",
                                 operand_build=spec.get("operand_build"),
                                 empty_rows=(plan.n_empty if plan is not None else 0),
-                                hop_tensors="compact (%d of %d vertices have stored entries)" % (plan.n_c, op.n) if plan is not None else "all vertices"),
+                                hop_tensors="compact (%d of %d vertices have stored entries)" % (plan.n_c, op.n) if plan is not None else "all vertices",
+                                time_steps_per_pass=(sorted(set(plan.q_chunk_cache.values())) if plan is not None and plan.q_chunk_cache else None)),
                     roofline=roofline, cpu_baseline=cpu)
     # ---- N > 1: the mandated vertex-sharded scheme (and the hybrid grid) on the same workload, reported next to the headline.
     # A watchdog on every rank prints the headline without them and ends the process if they overrun their budget.

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 
 def short(name):
-    for k in ("hop_fixup_kernel", "hop_kernel", "project_x3v2_kernel", "project_x3_kernel", "project_resident_kernel",
+    for k in ("hop_fixup_kernel", "hop_kernel", "project_x3_stream_kernel", "project_x3v2_kernel", "project_x3_kernel", "project_resident_kernel",
               "project_kernel", "project_narrow_kernel"):
         if k in name:
             return k
