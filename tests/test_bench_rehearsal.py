@@ -118,3 +118,25 @@ def test_one_rank_under_the_launcher_runs_the_collectives_and_the_extras():
     line = _json_lines(r.stdout)[0]
     assert line["n_gpus"] == 1 and line["config"]["dist_backend"] == "gloo"
     assert [(e["shard"], e["form"], e.get("exchange")) for e in line["other_shardings"]] == [("vertex", "plain", "allgather"), ("vertex", "overlapped", "allgather")]
+
+
+def test_the_drivers_eight_rank_command_on_the_cpu():
+    """The command an 8-GPU lease runs (`--gpus 8`, here self-launched, gloo, scipy stand-ins): 16 time steps split 2 per rank, the vertex-sharded
+    extras over all 8 ranks and the hybrid grid (4 groups x 2 vertex shards), one line, rc 0.  Control flow only -- nothing here is a measurement."""
+    r = _bare(["--gpus", "8", "--steps", "2", "--warmup", "1", "--rehearsal-cpu", "--vertices", "4000", "--entries", "50000", "--extras-budget", "240"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and "split over 8 ranks (2 on rank 0)" in line["config"]["sharding"]
+    assert "extras_abandoned" not in line, line.get("extras_abandon")
+    got = [(e["shard"], e["vertex_shards"], e["form"]) for e in line["other_shardings"]]
+    assert got == [("vertex", 8, "plain"), ("vertex", 8, "overlapped"), ("hybrid", 2, "plain"), ("hybrid", 2, "overlapped")], got
+    for e in line["other_shardings"]:
+        assert "error" not in e, e
+        assert len(e["ranks"]) == 8 and e["value"] > 0
+        if e["shard"] == "hybrid":
+            assert e["groups"] == 4 and e["time_steps_per_group"] == 4
+            assert sum(rk["owned_rows"] for rk in e["ranks"]) == 4 * 4000          # every group holds the whole graph
+        else:
+            assert sum(rk["owned_rows"] for rk in e["ranks"]) == 4000
