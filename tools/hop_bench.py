@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--lds-pads", default="0", help="comma list of hop_lds_pad values (KB): occupancy limiter, each crossed with --variants")
     ap.add_argument("--cold-last", type=int, default=None, help="reorder the entries inside every row: entries whose column is among the RANK most referenced "
                     "columns first (in column order), the others behind them (in column order) -- a gather instruction then carries lines of one latency class")
+    ap.add_argument("--xcd-classes", default=None, choices=["low", "shift", "hash"], help="XCD-specialised column classes WITHOUT extra segments: the entries of every row of more "
+                    "than 128 entries are regrouped by class(col) (then column), and the lane-group segments of class c are dealt to the workgroups that run on XCD c (block id %% 8), "
+                    "so that the eight 4-MB L2s hold disjoint column sets.  class = col %% 8 (low: round 3's experiment, fixes address bits 8-10), (col >> 4) %% 8 (shift) or a multiplicative hash")
     ap.add_argument("--reorder", default=None, help="GraphOperand.reordered(KIND) before anything else (degree | degree_sorted | rcm)")
     ap.add_argument("--cold-nt", action="store_true", help="with --cold-last: variant 5 runs on a copy of the entries whose COLD columns carry bit 31 "
                     "(hop_kernel gathers them with the non-temporal hint); every other variant runs on the plain entries")
@@ -104,10 +107,58 @@ def main():
             flagged = edges2.clone()
             flagged[cold_sorted, 0] |= -2147483648          # bit 31 of the column: "cold" (kNtColdGather in csrc/hop.h masks it off)
         del cold_sorted
+    def col_class(c):
+        if args.xcd_classes == "low":
+            return c % 8
+        if args.xcd_classes == "shift":
+            return (c >> 4) % 8
+        return ((c * 2654435761) >> 13) % 8
+    op_plain = op
+    if args.xcd_classes:
+        cols = op.edges[: op.nnz, 0].long()
+        counts = (op.rowptr[1:] - op.rowptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(op.n, device=dev), counts)
+        is_long = (counts > 128)[rows]
+        # the class order inside a row starts at class (row % 8): the segment that straddles two classes goes to the class of its first entry, and
+        # without the rotation class 0 would collect one extra segment per row (17 % more work for XCD 0)
+        key = rows * 8 + torch.where(is_long, (col_class(cols) - rows) % 8, torch.zeros_like(cols))
+        order = torch.argsort(key, stable=True)             # entries are sorted by column inside a row: stable keeps that inside every class
+        edges2 = op.edges[: op.nnz][order].contiguous()
+        print("xcd classes (%s): %d of %d entries sit in rows of more than 128 entries" % (args.xcd_classes, int(is_long.sum()), op.nnz), flush=True)
+        del cols, rows, is_long, key, order
+        op = graph.GraphOperand._from_packed(op.n, op.rowptr, edges2, op.nnz, n_cols=op.n_cols)
     lanes = _lib.lib().tgcn_hop_lanes_per_row(args.C // args.split, 1)
     scheds = {m: graph.Schedule(op.rowptr, op.n, lanes, edges=op.edges, seg_mode=m, n_cols=op.n_cols) for m in sorted(set(int(m) for m in args.seg_modes.split(",")))}
     for m, sm in scheds.items():
         print("seg_mode %d: blocks=%d segments=%d (whole-row wave segments %d) long rows=%d huge=%d partial slots=%d seg_len=%d" % (m, sm.nblk, sm.nseg, getattr(sm, "nwseg", 0), sm.nlong, sm.nhuge, sm.npartial, sm.seg_len), flush=True)
+    if args.xcd_classes:
+        # deal the lane-group segments (behind the whole-row wave segments) to the XCDs by the class of their first column: segment block j runs as
+        # workgroup nblk + nwblk + j, i.e. on XCD (nblk + nwblk + j) % 8; class lists keep the builder's order (by first column) and are padded
+        # with empty segments that write zeros into one dummy partial slot
+        assert set(scheds) == {0} and lanes == 16, "--xcd-classes: --seg-modes 0, 16-lane groups"
+        sm = scheds[0]
+        nw, ns, gpb = sm.nwseg, sm.nseg, 256 // lanes
+        seg_row, e0, e1, slot = [t[nw:ns].long() for t in (sm.seg_row, sm.seg_e0, sm.seg_e1, sm.seg_slot)]
+        cls = col_class(op.edges[e0, 0].long())
+        base = (sm.nblk + (nw + 3) // 4) % 8
+        cnt = torch.bincount(cls, minlength=8)
+        T = int(((cnt + gpb - 1) // gpb).max().item())
+        total = T * 8 * gpb
+        new = [torch.zeros(total, dtype=torch.int64, device=dev) for _ in range(3)] + [torch.full((total,), sm.npartial, dtype=torch.int64, device=dev)]
+        for c in range(8):
+            idx = (cls == c).nonzero().flatten()
+            k = torch.arange(idx.numel(), device=dev)
+            pos = ((k // gpb) * 8 + (c - base) % 8) * gpb + k % gpb
+            for dst, src in zip(new, (seg_row, e0, e1, slot)):
+                dst[pos] = src[idx]
+        cat = lambda a, b: torch.cat([a[:nw], b.to(torch.int32)]).contiguous()
+        sm.seg_row, sm.seg_e0, sm.seg_e1, sm.seg_slot = cat(sm.seg_row, new[0]), cat(sm.seg_e0, new[1]), cat(sm.seg_e1, new[2]), cat(sm.seg_slot, new[3])
+        sm.nseg, sm.npartial = nw + total, sm.npartial + 1
+        sm.struct = _lib.SchedStruct(sm.lanes_per_row, sm.row_thresh, sm.nblk, sm.nseg, sm.nlong, sm.nhuge, sm.npartial, sm.seg_mode, sm.row_mix, sm.nwseg,
+                                     sm.blk_row.data_ptr(), sm.seg_row.data_ptr(), sm.seg_e0.data_ptr(), sm.seg_e1.data_ptr(), sm.seg_slot.data_ptr(),
+                                     sm.long_row.data_ptr(), sm.long_slot.data_ptr())
+        op._sched[lanes] = sm
+        print("xcd classes: %d lane-group segments per class %s -> %d blocks per class, %d padding segments" % (ns - nw, cnt.tolist(), T, total - (ns - nw)), flush=True)
     s = op.schedule_for(args.C // args.split)
     print("n=%d nnz=%d blocks=%d segments=%d long rows=%d huge=%d partial slots=%d (T=%d S=%d)" % (op.n, op.nnz, s.nblk, s.nseg, s.nlong, s.nhuge, s.npartial, s.row_thresh, s.seg_len), flush=True)
     x = torch.randn(1, op.n_cols, args.C, device=dev)
@@ -146,6 +197,9 @@ def main():
     _lib.check(L.tgcn_set_tuning(b"hop_xcd_remap", 1))
     _lib.check(L.tgcn_set_tuning(b"hop_seg_remap", 0))
     _lib.check(L.tgcn_set_tuning(b"hop_mix", 0))
+    if args.xcd_classes:
+        yp = F.csr_hop(op_plain, x)
+        print("class-regrouped schedule vs plain: max rel err %.2e" % float((y - yp).abs().max() / yp.abs().max()), flush=True)
     alg = (8 * op.nnz + 4 * (op.n + 1)) / (16 if args.graph in ('rmat', 'banded') else 1) + 8 * op.n * args.C
     for v in variants:
         t = np.array(times[v])
