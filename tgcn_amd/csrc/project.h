@@ -820,34 +820,29 @@ __device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* ld
       *reinterpret_cast<unsigned*>(&W0[2 * NW * RS + wdst[h]]) = w3;
     }
   };
-  load_a(0, ra);
-  load_w(0);
-  store_w(0);
-  __syncthreads();
   const int frag = r16 * RS + x3_chunk(r16, kg) * 8;
-  for (int ti = 0; ti < total; ++ti) {
-    float rn[RT][8];
-    const bool more = ti + 1 < total;
-    if (more) { load_a(ti + 1, rn); load_w(ti + 1); }
-    bf16x8 a[RT][3];
+  // split the 8 floats per row tile of a wave into the three bf16 planes (the MFMA A operands of one k tile)
+  auto split_a = [&](const float (&src)[RT][8], bf16x8 (&dst)[RT][3]) {
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       unsigned pl[3][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) split3(ra[r][2 * j], ra[r][2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
+      for (int j = 0; j < 4; ++j) split3(src[r][2 * j], src[r][2 * j + 1], pl[0][j], pl[1][j], pl[2][j]);
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-        a[r][q] = __builtin_bit_cast(bf16x8, u32x4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+        dst[r][q] = __builtin_bit_cast(bf16x8, u32x4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
       }
     }
-    const unsigned short* W0 = Wp + (ti & 1) * WBUF;
+  };
+  // the MFMAs of column tiles [nt0, nt1) of one k tile: smallest terms first; the row tiles of a wave alternate so that consecutive MFMAs are independent
+  auto mfma_tiles = [&](const bf16x8 (&a)[RT][3], const unsigned short* W0, const int nt0, const int nt1) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      if (nt < nt0 || nt >= nt1) continue;
       bf16x8 w[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) w[q] = *reinterpret_cast<const bf16x8*>(&W0[q * NW * RS + (nt * 16) * RS + frag]);
-      // smallest terms first; the row tiles of a wave alternate so that consecutive MFMAs are independent
       f32x4 c[RT];
 #pragma unroll
       for (int r = 0; r < RT; ++r) c[r] = acc[r][nt];
@@ -866,6 +861,110 @@ __device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* ld
 #pragma unroll
       for (int r = 0; r < RT; ++r) acc[r][nt] = c[r];
     }
+  };
+  int ti = 0;
+  load_a(0, ra);
+  load_w(0);
+  store_w(0);
+  // ---- software-pipelined main loop (round 5, wide outputs).  The plain loop below runs every k tile as three PHASES -- split the A rows
+  // (~90 vector instructions), 12 * NT MFMAs, split + stage the next W tile (~60 vector instructions) -- and with one barrier per tile both waves of
+  // a SIMD are in the same phase: SQ_VALU_MFMA_COEXEC_CYCLES was 4 % of SQ_VALU_MFMA_BUSY_CYCLES on cfg4 (matrix pipe 36 % busy, profiles/
+  // r05_cfg4_projection_sq.json).  Here an iteration multiplies tile t while the SAME basic block splits the A rows of tile t+1 and splits + stages
+  // W of tile t+1 (so that the scheduler can place that vector work next to the MFMAs -- it puts the W split between the MFMAs of the second half
+  // and the A split behind them), and the loads of tile t+2 are issued in the MIDDLE of the iteration, as soon as the registers they fill are free:
+  // one and a half iterations of slack instead of one.  cfg4 (90,000 x 1200 x 160): 0.277 -> 0.212 ms.  Forcing an instruction-level
+  // MFMA / vector interleave in the first half too (slices of the split pinned between fences by empty asm statements) or issuing each W pair's
+  // load right after its split measured 0.219 / 0.225 ms: not it (docs/EXPERIMENTS.md A.5).  Only full 32-k tiles run here; the last two (and a
+  // partial one) drain through the plain loop.  Bitwise the plain loop's result (same products, same order).
+  const int nfull = (p.Kc % KT == 0) ? total : (p.nterms == 1 ? ktiles - 1 : 0);
+  if (NT >= 6 && nfull >= 4 && !p.rowmap) {
+    float rn[RT][8];
+    bf16x8 a_cur[RT][3], a_next[RT][3];
+    auto load_a_full = [&](int t, float (&dst)[RT][8]) {            // full tiles only: no bounds on k
+      const int term = t / ktiles, k0 = (t % ktiles) * KT;
+      const float* __restrict__ A = p.a[term] + k0 + kg * 8;
+      const int64_t lda = p.lda[term];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 v = *reinterpret_cast<const float4*>(A + rowc[r] * lda + h * 4);           // (no row map on this path)
+          dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
+        }
+    };
+    auto load_w_full = [&](int t) {                                  // unconditional loads (wsrc is clamped into the tile) + select: no branch in the loop body
+      const int term = t / ktiles, k0 = (t % ktiles) * KT;
+      const float* __restrict__ Wt = p.W + ((int64_t)term * p.Kc + k0) * p.N;
+#pragma unroll
+      for (int h = 0; h < WPAIRS; ++h) {
+        const float v0 = Wt[wsrc[h]], v1 = Wt[wsrc[h] + p.N];
+        rw[h * 2 + 0] = wcol[h] ? v0 : 0.f;
+        rw[h * 2 + 1] = wcol[h] ? v1 : 0.f;
+      }
+    };
+    split_a(ra, a_cur);
+    load_a_full(1, rn);
+    load_w_full(1);
+    __syncthreads();
+    for (; ti + 2 < nfull; ++ti) {                   // invariant: a_cur = planes of tile ti, rn / rw = raw A / W of tile ti+1, LDS buffer ti & 1 = W planes of tile ti
+      const unsigned short* W0 = Wp + (ti & 1) * WBUF;
+      mfma_tiles(a_cur, W0, 0, NT / 2);
+      split_a(rn, a_next);                           // tile ti+1 (its loads were issued in the middle of the previous iteration)
+      // requested order of the first half: per column tile its 3 fragment reads, then its 6 * RT MFMAs two at a time with vector instructions between
+#pragma unroll
+      for (int i = 0; i < NT / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int j = 0; j < 3 * RT; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_a_full(ti + 2, rn);
+      mfma_tiles(a_cur, W0, NT / 2, NT);
+      store_w((ti + 1) & 1);                         // split + stage W of tile ti+1 into the other buffer (free since the barrier of iteration ti-1)
+      // second half: the W split (about 11 vector instructions per pair of weights and 3 LDS writes) between the MFMAs
+#pragma unroll
+      for (int i = 0; i < NT - NT / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int j = 0; j < 3 * RT; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+      }
+      load_w_full(ti + 2);
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_cur[r][q] = a_next[r][q];
+      __syncthreads();
+    }
+    // hand over to the plain loop at tile ti: it wants the RAW rows of tile ti in `ra` -- they are gone (only the planes are kept), so the plain
+    // loop's first iteration is done here by hand: multiply tile ti from a_cur, stage W of ti+1, raw rows of ti+1 become `ra`
+    {
+      const unsigned short* W0 = Wp + (ti & 1) * WBUF;
+      mfma_tiles(a_cur, W0, 0, NT);
+      store_w((ti + 1) & 1);
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ra[r][j] = rn[r][j];
+      __syncthreads();
+      ++ti;
+    }
+  } else {
+    __syncthreads();
+  }
+  for (; ti < total; ++ti) {
+    float rn[RT][8];
+    const bool more = ti + 1 < total;
+    if (more) { load_a(ti + 1, rn); load_w(ti + 1); }
+    bf16x8 a[RT][3];
+    split_a(ra, a);
+    mfma_tiles(a, Wp + (ti & 1) * WBUF, 0, NT);
     if (more) {
       store_w((ti + 1) & 1);
 #pragma unroll

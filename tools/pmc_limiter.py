@@ -43,6 +43,10 @@ CANDIDATES = collections.OrderedDict([
                 "SQ_INST_LEVEL_VMEM", "SQ_INSTS_VMEM", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_FLAT",
                 "SQ_BUSY_CU_CYCLES", "SQ_CYCLES"])),
     ("GRBM", (2, ["GRBM_GUI_ACTIVE", "GRBM_COUNT"])),
+    # matrix pipe and LDS of the MFMA kernels (projection): --only-blocks SQX,SQ,GRBM
+    ("SQX", (8, ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+                 "SQ_LDS_ADDR_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VALU2", "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL", "SQ_LDS_UNALIGNED_STALL",
+                 "SQ_INSTS_VALU_MFMA_BF16", "SQ_ACTIVE_INST_MISC", "SQ_ACTIVE_INST_SCA"])),
 ])
 
 
