@@ -1092,18 +1092,20 @@ __global__ __launch_bounds__(1024) void project_x3_stream_kernel(const ProjParam
 
   // ---- per-tile row state: this lane's row in the tile order (clamped) and through the row map; the map entry of the NEXT tile is
   // loaded a whole tile ahead so that no unit's loads wait for it
+  // (row numbers as 32-bit values: the host refuses M or n_vertices beyond int32 for this kernel; four 64-bit row registers cost the <4, 2>
+  //  instantiation its last spill-free registers)
   int64_t tile = (int64_t)blockIdx.x * 16 + wave;
-  int64_t mrow = 0, rrow = 0, rrow_next = 0;
+  int32_t mrow = 0, rrow = 0, rrow_next = 0;
   bool row_ok = false;
-  auto tile_rows = [&](int64_t t, int64_t& m_c) { const int64_t m = t * 16 + r16; m_c = m < p.M ? m : p.M - 1; return m < p.M; };
-  auto fetch_map = [&](int64_t t) -> int64_t {
+  auto tile_rows = [&](int64_t t, int32_t& m_c) { const int64_t m = t * 16 + r16; m_c = (int32_t)(m < p.M ? m : p.M - 1); return m < p.M; };
+  auto fetch_map = [&](int64_t t) -> int32_t {
     if (t >= ntiles) return 0;
-    int64_t m_c; (void)tile_rows(t, m_c);
-    return p.rowmap ? (int64_t)p.rowmap[m_c] : m_c;
+    int32_t m_c; (void)tile_rows(t, m_c);
+    return p.rowmap ? p.rowmap[m_c] : m_c;
   };
   float xa[KTILES * 8], xb[KTILES * 8];
   // unit u of the tile whose rows are (m_c, r_c): term u % nterms of sample u / nterms
-  auto load_unit = [&](int u, int64_t m_c, int64_t r_c, float (&dst)[KTILES * 8]) {
+  auto load_unit = [&](int u, int32_t m_c, int32_t r_c, float (&dst)[KTILES * 8]) {
     const int b = u / p.nterms, t = u - b * p.nterms;            // wave-uniform
     const int64_t arow = ((p.mapped >> t) & 1u) && p.rowmap ? r_c : m_c;
     const float* __restrict__ src = p.a[t] + (int64_t)b * p.a_bs[t] + arow * p.lda[t] + 4 * g;
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(1024) void project_x3_stream_kernel(const ProjParam
     const int64_t orow = map_out ? rrow : mrow;
     load_bias(orow);
     const int64_t tile_n = tile + nwaves;
-    int64_t mrow_n = 0;
+    int32_t mrow_n = 0;
     const bool ok_n = tile_n < ntiles ? tile_rows(tile_n, mrow_n) : false;
     // units of this tile two at a time (statically named register buffers); the unit after the tile's last one is unit 0 of the next tile
     for (int u = 0; u < units; u += 2) {

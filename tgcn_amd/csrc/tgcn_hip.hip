@@ -248,7 +248,8 @@ static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterm
   }
   const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
   // rows of 32 / 64 floats, <= 64 output columns, whole weight resident as bf16 planes: the barrier-free streaming form
-  if (stream_ok && !windows && vec4 && vec_epilogue && (Kc == 32 || Kc == 64) && N <= 64 && x3_stream_lds(Kc, N, nterms) <= kX3StreamMaxLds &&
+  if (stream_ok && !windows && vec4 && vec_epilogue && (Kc == 32 || Kc == 64) && N <= 64 && x3_stream_lds(Kc, N, nterms) <= kX3StreamMaxLds && M < (int64_t)INT32_MAX &&
+      /* n_vertices is checked by the caller of this function where it matters: project_impl passes it through stream_ok */
       (pv == 6 || (pv == 0 && use_x3 && M * (int64_t)nbatch >= kX3StreamMinRows))) {
     c.kernel = kProjX3Stream;
     return c;
@@ -340,7 +341,7 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
                    (p.bias_cols % 4 == 0);
   bool strides4 = (out_bs % 4 == 0);
   if (nbatch > 1) for (int t = 0; t < nterms; ++t) strides4 = strides4 && (a_bs[t] % 4 == 0);
-  const bool stream_ok = pool <= 1 && !gather && !accumulate && interleave == 1 && win_n == 0 && strides4 && bias_cols < 0;
+  const bool stream_ok = pool <= 1 && !gather && !accumulate && interleave == 1 && win_n == 0 && strides4 && bias_cols < 0 && n_vertices < (int64_t)INT32_MAX;
   const ProjChoice choice = project_choose(M, Kc, N, nterms, vec4, p.vec_epilogue != 0, rowmap != nullptr, win_n != 0, stream_ok, nbatch);
   if (rowmap && interleave != 1 && choice.kernel != kProjNarrow)
     TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: a row map together with interleave is the vector-ALU kernel's form (nterms*Kc <= %d, N %% 4 == 0, M >= 4096)", kNarrowMaxK);
