@@ -273,7 +273,10 @@ def test_hop_linearity_large(gpu_device):
 @pytest.mark.parametrize("M,Kc,N,T,inter", [(100, 1, 8, 5, 1), (1000, 28, 64, 5, 1), (777, 64, 64, 3, 1), (640, 15, 32, 10, 1),
                                             (333, 7, 5, 2, 1), (1200, 12, 15, 4, 4), (64 * 9, 3, 100, 2, 9), (500, 36, 40, 33, 1),
                                             (5000, 64, 64, 5, 1), (4100, 200, 32, 3, 1), (70, 130, 17, 2, 1), (20000, 64, 64, 5, 1), (9000, 100, 160, 1, 1),
-                                            (6000, 1, 64, 5, 16), (4099, 4, 256, 4, 1), (5000, 2, 1024, 8, 1), (4500, 1, 32, 33, 1)])
+                                            (6000, 1, 64, 5, 16), (4099, 4, 256, 4, 1), (5000, 2, 1024, 8, 1), (4500, 1, 32, 33, 1),
+                                            # the software-pipelined loop of the wide bf16x3 kernel (variant 3): exactly 4 full k tiles (2 pipelined iterations);
+                                            # 3 terms x 2 tiles across term boundaries; 37 full tiles + a half one (cfg4's contraction); 96 / 128 columns
+                                            (3000, 128, 160, 1, 1), (2000, 64, 96, 3, 1), (1500, 1200, 160, 1, 1), (2500, 160, 128, 2, 1), (700, 96, 100, 1, 1)])
 @pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 6])
 def test_project_vs_numpy(M, Kc, N, T, inter, variant, gpu_device):
     """variant 6: the barrier-free streaming bf16x3 kernel wherever the shape has it (rows of 32 / 64 floats, <= 64 columns; the shipped
