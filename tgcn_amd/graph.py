@@ -15,7 +15,7 @@ from . import _lib
 ROW_THRESH = 32         # rows with more stored entries are processed as column-ordered segments
 SEG_LEN = 32            # stored entries per segment (measured on cfg5: 32 beats 16/64/128/256, tools/hop_bench.py)
 SEG_MODE = 0            # 0: one lane group per segment (shipped); 1: one WAVE per segment of SEG_LEN * (64 / lanes) entries, pieces folded in
-                        # the wave -- 4.7x fewer partial rows but the column-ordered sweep loses its locality: cfg5 hop 3.82 -> 4.44 ms
+                        # the wave -- 4.7x fewer partial rows but the column-ordered sweep loses its locality: cfg5 hop 3.82 -> 4.44 ms (docs/EXPERIMENTS.md A.3)
 SEG_KEY = "first"       # column of the segment used as its place in the processing order
 WAVE_ROWS = True        # 16-lane schedules: rows with ROW_THRESH < entries <= 128 are whole-row segments of one WAVE each (its lane groups fold inside the
                         # wave: no partial rows, no fix-up for them; cfg5: fix-up 0.216 -> 0.155 ms per launch, hop unchanged); False: lane-group segments
