@@ -111,7 +111,8 @@ def test_spmm_is_differentiable_in_value_and_matrix(fn, shape, gpu_device):
     assert rel_err(M.grad.cpu().numpy(), Md.grad.cpu().numpy()) <= GRAD_TOL
 
 
-@pytest.mark.parametrize("n,E,f,g,K,small", [(60, 400, 4, 5, 3, True), (3000, 30000, 16, 8, 4, False), (70000, 200000, 8, 8, 3, False)])
+@pytest.mark.parametrize("n,E,f,g,K,small", [(60, 400, 4, 5, 3, True), (3000, 30000, 16, 8, 4, False), (70000, 200000, 8, 8, 3, False),
+                                             (32, 900, 4, 5, 3, True)])          # the last: an operand that also keeps a DENSE copy (matrix-pipe kernels), refreshed too
 def test_training_with_learnable_edge_weights_keeps_one_operand(n, E, f, g, K, small, gpu_device, monkeypatch):
     """every optimizer step bumps edge_weight's version; the operand cache used to key on it -- a full edge normalise +
     COO -> CSR sort + schedule per step and up to 16 stale operands (each with its lazily built transpose and compact plans) kept alive.  Now
@@ -143,6 +144,7 @@ def test_training_with_learnable_edge_weights_keeps_one_operand(n, E, f, g, K, s
         assert len(ops) == 1 and len(layer._ops._d) <= 2, list(layer._ops._d)          # one operand + the (src, coef) links
         first_op = first_op or ops[0]
         assert ops[0] is first_op and ops[0]._transpose is not None                     # same object: schedules / transpose built once
+        assert (ops[0].dense is not None) == (n == 32)
         # a fresh module with the current parameters and a weight tensor that was never seen before
         fresh = copy.deepcopy(layer)
         w2 = w.detach().clone().requires_grad_(True)
