@@ -603,7 +603,15 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         prof = [] if rehearsal else _lib.profile_stop(65536)
+    per_rank = None
     if dist is not None:
+        # what every rank measured on its own (the headline is the MAX): a scaling run that comes out below N x is read from these -- a slow rank,
+        # a rank with more time steps, a rank whose hop launches are slower -- without a second run
+        mine = dict(rank=rank, time_steps=spec["q"] * spec["H"], ms_per_step=round(dt / args.steps * 1e3, 3),
+                    hop_mean_launch_ms=(round(float(np.mean([ms for kind, ms in prof if kind == 0])), 4) if any(kind == 0 for kind, _ in prof) else None),
+                    device=(torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu"))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -745,6 +753,8 @@ def main():
                                 hop_tensors="compact (%d of %d vertices have stored entries)" % (plan.n_c, op.n) if plan is not None else "all vertices",
                                 time_steps_per_pass=(sorted(set(plan.q_chunk_cache.values())) if plan is not None and plan.q_chunk_cache else None)),
                     roofline=roofline, cpu_baseline=cpu)
+        if per_rank is not None:
+            line["ranks"] = per_rank
     # ---- N > 1: the mandated vertex-sharded scheme (and the hybrid grid) on the same workload, reported next to the headline.
     # A watchdog on every rank prints the headline without them and ends the process if they overrun their budget.
     if dist is not None and (world > 1 or args.force_extras) and args.shard == "time" and not args.no_extras and spec["cls"] in ("TGCNCheb", "TGCNCheb_H"):

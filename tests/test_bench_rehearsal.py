@@ -39,6 +39,8 @@ def test_strong_time_sharding_and_extras_at_world_2():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert "split over 2 ranks (8 on rank 0)" in line["config"]["sharding"]
+    assert [r["rank"] for r in line["ranks"]] == [0, 1] and all(r["time_steps"] == 8 and r["ms_per_step"] > 0 for r in line["ranks"])
+    assert line["ms_per_step"] >= max(r["ms_per_step"] for r in line["ranks"]) - 1e-3          # the headline is the slowest rank
     assert "extras_abandoned" not in line
     extras = line["other_shardings"]
     assert [(e["shard"], e["form"]) for e in extras] == [("vertex", "plain"), ("vertex", "overlapped")]
