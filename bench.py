@@ -484,7 +484,20 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool: RCCL's cross-process handles need it
     env.setdefault("OMP_NUM_THREADS", "1")
     print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env, cwd=ROOT)
+    import signal
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)      # its own process group: the ranks can be ended with it
+
+    def forward(signum, _frame):          # a parent that is told to stop takes its ranks with it (exact process group, never a pattern)
+        try:
+            os.killpg(child.pid, signum)
+        except ProcessLookupError:
+            pass
+    old = {sig: signal.signal(sig, forward) for sig in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        return child.wait()
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
 
 
 def main():

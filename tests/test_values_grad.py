@@ -155,11 +155,19 @@ def test_training_with_learnable_edge_weights_keeps_one_operand(n, E, f, g, K, s
         for a, b in ((w.grad, w2.grad), (xin.grad, x2.grad), (layer.weight.grad, fresh.weight.grad)):
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= GRAD_TOL
         opt.step()
-    # a COMPUTED weight (new tensor every forward, as from a small network): still one operand
+    # a COMPUTED weight (new tensor every forward, as from a small network): still one operand -- and never stale: each forward's weight is freed
+    # before the next one is made, so the allocator hands the SAME address (version 0 again) to a tensor with other values
     scale = torch.nn.Parameter(torch.ones((), device="cuda"))
-    for _ in range(3):
-        out = layer(x, ei, w.detach() * scale)
+    seen = set()
+    for it in range(4):
+        wc = w.detach() * (scale * (1.0 + 0.25 * it))
+        seen.add(wc.data_ptr())
+        out = layer(x, ei, wc)
         out.sum().backward()
+        with torch.no_grad():
+            want = copy.deepcopy(layer)(x, ei.clone(), (w.detach() * (1.0 + 0.25 * it)).clone())
+        assert rel_err(out.detach().cpu().numpy(), want.cpu().numpy()) <= 2e-6, it
+        del wc, out
     assert len([v for v in layer._ops._d.values() if isinstance(v[0], graph.GraphOperand)]) == 1
     assert scale.grad is not None and torch.isfinite(scale.grad)
 

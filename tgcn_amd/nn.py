@@ -223,14 +223,20 @@ def _stamp(t):
     return (t.data_ptr(), t._version)
 
 
-def _refresh_values(op, stamp, make_vals):
+def _refresh_values(op, weight, make_vals):
     """A LEARNABLE weight changes every optimizer step (and a computed one is a new tensor every forward) while the pattern stays: the operand is
     cached by pattern and only its packed values are refreshed in place (GraphOperand.update_values) -- a cache keyed on the weight's version would
-    rebuild CSR, schedule and transpose per step and keep up to 16 stale operands alive."""
+    rebuild CSR, schedule and transpose per step and keep up to 16 stale operands alive.
+    "Has the weight changed" = (data_ptr, _version) against the stamp of the last packing.  That pair only names a tensor while its storage is
+    alive -- a freed weight's address can be handed to the next one, version 0 again -- so the operand holds the detached alias of the tensor it
+    was packed from (shares storage and version counter, keeps no autograd graph): same address then means same storage, and its version counter
+    says whether it was written."""
+    stamp = _stamp(weight)
     if getattr(op, "_packed_stamp", None) != stamp:
         with op._lock:
             if getattr(op, "_packed_stamp", None) != stamp:
                 op.update_values(make_vals())
+                op._packed_alias = weight.detach()
                 op._packed_stamp = stamp
     return op
 
@@ -240,13 +246,8 @@ def _coo_operand(index, value, m, device, n_cols=None):
     n_cols = int(m if n_cols is None else n_cols)
     if value.requires_grad:          # learnable values: one operand per PATTERN, values refreshed in place
         key = ("learnable", _tensor_key(index), int(m), n_cols, str(device))
-        first = []
-        op = _spmm_ops.get(key, lambda: (first.append(1), GraphOperand.from_coo(int(m), index[0], index[1], value.detach(), device, n_cols=n_cols))[1],
-                           sources=(index,))
-        if first:
-            op._packed_stamp = _stamp(value)
-            return op
-        return _refresh_values(op, _stamp(value), lambda: value.detach().to(device=op.device, dtype=torch.float32).reshape(-1)[_coo_order(index, op)])
+        op = _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value.detach(), device, n_cols=n_cols), sources=(index,))
+        return _refresh_values(op, value, lambda: value.detach().to(device=op.device, dtype=torch.float32).reshape(-1)[_coo_order(index, op)])
     key = (_tensor_key(index), _tensor_key(value), int(m), n_cols, str(device))
     return _spmm_ops.get(key, lambda: GraphOperand.from_coo(int(m), index[0], index[1], value.detach(), device, n_cols=n_cols),
                          sources=(index, value.detach()))      # the detached alias shares storage and version counter: the address cannot be reused, no graph is kept
@@ -307,15 +308,14 @@ class _EdgeBase(torch.nn.Module):
         if edge_weight is not None and edge_weight.requires_grad:
             # learnable weights: ONE operand per edge_index; the values lap_e = coef_e * w_e are refreshed in place when the weight has changed
             key = ("learnable", _tensor_key(edge_index), n, str(x.device))
-            first = []
-            op = self._ops.get(key, lambda: (first.append(1), GraphOperand.from_edge_index(edge_index, w, n, x.device))[1], sources=(edge_index,))
+            op = self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, w, n, x.device), sources=(edge_index,))
 
             def vals():
                 src, coef = self._links(edge_index, n, x.device)
                 return coef * w.to(device=x.device, dtype=torch.float32).reshape(-1)[src]
             # (the first build's values are re-packed by the same formula as every later refresh, so that equal weights give bit-equal
             # operands whatever the history of the module: the builder rounds -d^-1/2 w d^-1/2 in another order)
-            return _refresh_values(op, _stamp(edge_weight), vals)
+            return _refresh_values(op, edge_weight, vals)
         key = (_tensor_key(edge_index), _tensor_key(edge_weight), n, str(x.device))
         return self._ops.get(key, lambda: GraphOperand.from_edge_index(edge_index, w, n, x.device), sources=(edge_index, w))
 
