@@ -337,8 +337,8 @@ class GraphOperand:
         if self.dense is not None:
             counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
             rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), counts)
-            self.dense.zero_()
-            self.dense.index_put_((rows, self.edges[: self.nnz, 0].to(torch.int64)), vals, accumulate=True)
+            # (coalesce sums duplicates in a fixed order, like the first build; index_put_(accumulate=True) would use float atomics)
+            self.dense.copy_(torch.sparse_coo_tensor(torch.stack([rows, self.edges[: self.nnz, 0].to(torch.int64)]), vals, (self.n, self.n)).coalesce().to_dense())
         with self._lock:
             plans = [pl for pl in (self._compact or {}).values() if pl is not None] if self._compact is not False else []
             for pl in plans:
