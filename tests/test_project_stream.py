@@ -78,3 +78,40 @@ def test_stream_kernel_is_the_shipped_choice_for_the_compact_forward_shapes(gpu_
     ref = (ref.reshape(q, nv, N) + bias).reshape(M, N)
     out = F.cheb_project([_dev(t) for t in terms], _dev(W), _dev(bias), 2, nv)
     assert rel_err(out.cpu().numpy(), ref) <= TOL
+
+
+def test_stream_kernel_with_the_map_on_the_terms_only(gpu_device, monkeypatch):
+    """tgcn_set_tuning("compact_proj", 1): ONE projection launch over all vertices in order -- output and bias rows are the tile rows, the
+    hop tensors are read through the vertex -> compact-id map (empty vertices point at the zero row): the kProjMapTermsOnly form of the row map,
+    which the streaming kernel takes from 32768 rows.  Against the two-launch default and against float64."""
+    import scipy.sparse as sp
+    from tgcn_amd import functional as F, graph, _lib
+    monkeypatch.setattr(graph, "COMPACT_MIN_ROWS", 1)
+    rng = np.random.default_rng(17)
+    n, q, C, N, K = 50000, 3, 64, 64, 4
+    live = rng.permutation(n)[: n // 2]
+    m = 200000
+    u, v = live[rng.integers(0, live.size, m)], live[(rng.random(m) ** 2 * live.size).astype(np.int64)]
+    row, col = np.concatenate([u, v]), np.concatenate([v, u])
+    val = (rng.standard_normal(row.size) / 5).astype(np.float32)
+    op = graph.GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    plan = op.compact_plan()
+    assert plan is not None and plan.n_empty >= n // 2
+    x = rng.standard_normal((q, n, C)).astype(np.float32)
+    W = (rng.standard_normal((K, C, N)) / np.sqrt(K * C)).astype(np.float32)
+    bias = rng.standard_normal((n, N)).astype(np.float32)
+    Ls = sp.coo_matrix((val.astype(np.float64), (row, col)), shape=(n, n)).tocsr()
+    P = [x.astype(np.float64)]
+    for _ in range(1, K):
+        P.append(np.stack([Ls @ P[-1][b] for b in range(q)]))
+    ref = sum(P[k] @ W[k].astype(np.float64) for k in range(K)) + bias
+    W2 = _dev(W.reshape(K * C, N))
+    outs = {}
+    for mode in (0, 1):
+        _lib.check(_lib.lib().tgcn_set_tuning(b"compact_proj", mode))
+        _lib.profile_start(256)
+        outs[mode] = F.cheb_forward_compact(plan, _dev(x), W2, _dev(bias), 2, K, q_chunk=q).cpu().numpy()
+        prof = _lib.profile_stop(256)
+        assert sum(1 for kind, _ in prof if kind == 2) == (1 if mode else 2)
+        assert rel_err(outs[mode], ref) <= TOL
+    assert rel_err(outs[1], outs[0]) <= 2e-6
