@@ -146,3 +146,48 @@ def test_bench_n_gt_1_path_on_rccl_one_rank(gpu_device):
     assert forms == [("vertex", "plain", "allgather", False), ("vertex", "overlapped", "allgather", False)], line["other_shardings"]
     for e in line["other_shardings"]:
         assert e["value"] > 0 and e["ranks"][0]["owned_rows"] == 200000 and e["ranks"][0]["phases_ms"]
+
+
+def _nccl_peers_worker(rank, world, port, exchange, banded, ret):
+    """the two-rank test above with REAL peers: rank r on cuda:r, RCCL transport (runs only where the box has the GPUs)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from tgcn_amd.dist import VertexShardedCheb
+        rng = np.random.default_rng(3)
+        n, q, C, N, K = 3000, 3, 8, 12, 4
+        if banded:
+            row = np.repeat(np.arange(n), 6)
+            col = np.clip(row + rng.integers(-9, 10, row.shape[0]), 0, n - 1)
+        else:
+            row, col = rng.integers(0, n, 8 * n), rng.integers(0, n, 8 * n)
+        val = (rng.standard_normal(row.shape[0]) / 3).astype(np.float32)
+        x = rng.standard_normal((q, n, C)).astype(np.float32)
+        W = (rng.standard_normal((K, C, N)) / 4).astype(np.float32)
+        bias = rng.standard_normal((n, N)).astype(np.float32)
+        sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), device=dev, exchange=exchange)
+        args = (torch.as_tensor(x[:, sh.lo:sh.hi]).to(dev), torch.as_tensor(W).to(dev), torch.as_tensor(bias[sh.lo:sh.hi]).to(dev), 2, 1)
+        out = sh.forward(*args)
+        plain = sh.forward(*args, overlap=False)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(out, plain))
+        L = O.coo_to_csr(row, col, val, n)
+        ref = np.einsum("kqnc,kcg->qng", O.stack_chebyshev(L, x, K).astype(np.float64), W.astype(np.float64)) + bias
+        err = np.abs(out.cpu().numpy() - ref[:, sh.lo:sh.hi]).max() / np.abs(ref).max()
+        ret[rank] = (float(err), sh.exchange, sh.owned, same)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL between real peers)")
+@pytest.mark.parametrize("exchange,banded", [("halo", True), ("allgather", False)])
+def test_vertex_sharded_two_ranks_two_gpus_rccl(exchange, banded):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_peers_worker, args=(world, _free_port(), exchange, banded, ret), nprocs=world, join=True)
+    assert len(ret) == world and sum(ret[r][2] for r in range(world)) == 3000
+    for r in range(world):
+        assert ret[r][0] <= 1e-5 and ret[r][1] == exchange and ret[r][3], ret[r]
