@@ -191,7 +191,7 @@ def scipy_baseline(op, spec, x, cols=8):
                 sample="%d of the %d columns of 1 of %d samples, K=%d recursion only (no projection), scipy CSR .dot single thread as gcn/graph.py:256-265, %.1f s" % (cols, C_row, spec["q"], spec["K"], dt))
 
 
-def torch_dense_baseline(op, spec, layer, x):
+def torch_dense_baseline(op, spec, layer, x, seconds=3.0):
     """SURVEY.md 8(d) baseline (ii), small graphs only: the reference's own evaluation order on the CPU -- torch einsum with the
     dense (n, n) operand -- through oracle.cheb_oracle.torch_dense_forward, all host threads torch uses by default."""
     from oracle import cheb_oracle as O
@@ -206,7 +206,7 @@ def torch_dense_baseline(op, spec, layer, x):
     O.torch_dense_forward(Ld, xc[:1], W, b, horizon)          # warm-up
     t0 = time.perf_counter()
     reps = 0
-    while time.perf_counter() - t0 < 3.0:
+    while time.perf_counter() - t0 < seconds:
         out = O.torch_dense_forward(Ld, xc, W, b, horizon)
         reps += 1
     dt = (time.perf_counter() - t0) / reps
@@ -234,38 +234,111 @@ def cpu_baseline(op, spec, layer, x, samples=(0,)):
     out = c_port.forward(0, rowptr, col, val, xs, W, b, kind)
     dt = time.perf_counter() - t0
     units = op.nnz * (K - 1) * q * spec["H"]
-    return out, dict(value=units / dt / 1e9, unit="G edge\u00b7timesteps/s", cores=c_port.threads(), kind="port",
+    return out, dict(value=units / dt / 1e9, unit="G edge\u00b7timesteps/s", cores=c_port.threads(), kind="port", seconds=round(dt, 2), samples_timed=list(samples),
                      sample="samples %s of the %d of the same workload, full K=%d forward, oracle/cheb_ref.c OpenMP, %.1f s" % (samples, spec["q"], K, dt))
+
+
+def host_description():
+    """every CPU number is printed with the host it was measured on"""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(cpu_model=model, os_cpu_count=os.cpu_count(), torch_num_threads=torch.get_num_threads(), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS"),
+                sched_affinity=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None)
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
+MFMA_F32_PEAK_TFLOPS = 157.3        # fp32 matrix peak
+
+
+def other_workload_entry(name, device, steps=20, warmup=5):
+    """One of BASELINE.json's other configurations (cfg2 f = 1 / 64, cfg3, cfg4) in the driver's record: ms per forward,
+    the roofline of ITS dominant kernel from the library's launch events, and the GPU result against the CPU restatements."""
+    from tgcn_amd import _lib, functional as _F
+    t_start = time.perf_counter()
+    op, spec = build_workload(name, "natural", device)
+    layer = make_layer(op, spec, device)
+    x = make_input(op, spec, device, seed=0)
+    K, q, H = spec["K"], spec["q"], spec["H"]
+    C_row, g_ch = H * spec["f"], spec["g"]
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = layer(x)
+        torch.cuda.synchronize()
+        _lib.profile_start(8192)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = layer(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = _lib.profile_stop(8192)
+    units = op.nnz * (K - 1) * q * H
+    entry = dict(workload=spec["desc"], config=name, ms_per_step=round(dt / steps * 1e3, 4), value=round(units * steps / dt / 1e9, 3), unit="G edge\u00b7timesteps/s",
+                 steps=steps, warmup=warmup, dtype="f32")
+    by_kind = {}
+    for kind, ms in prof:
+        by_kind.setdefault(kind, []).append(ms)
+    names = {0: "hop_kernel", 1: "hop_fixup_kernel", 2: "projection", 3: "relayout_kernel", 4: "small_forward_kernel"}
+    entry["kernel_ms_per_step"] = {names.get(k, str(k)): round(float(np.sum(v)) / steps, 4) for k, v in sorted(by_kind.items())}
+    dom = max(by_kind, key=lambda k: float(np.sum(by_kind[k]))) if by_kind else None
+    pf = _F.use_project_first(q, op.n, C_row, g_ch) and not _F.small_path_tile(op, C_row, 0)
+    F_cols = q * (g_ch if pf else C_row)
+    bytes_recursion = (K - 1) * (8 * op.nnz + 4 * (op.n + 1) + 8 * op.n * F_cols)
+    if dom == 4:
+        layer_bytes = bytes_recursion + 4 * op.n * q * g_ch + 4 * K * C_row * g_ch + 4 * layer.bias.numel()
+        mean_ms = float(np.mean(by_kind[4]))
+        ach = layer_bytes / (mean_ms * 1e-3) / 1e9
+        entry["roofline"] = dict(bound="hbm", kernel="small_forward_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
+                                 traffic=None, algorithmic_bytes_per_launch=int(layer_bytes), mean_launch_ms=round(mean_ms, 4),
+                                 launches_per_step=len(by_kind[4]) // steps,
+                                 note="whole layer in one launch (CSR + activations in LDS): latency-bound configuration, BASELINE.md 4 sets no bar")
+    elif dom == 2:
+        mean_ms = float(np.sum(by_kind[2])) / steps
+        flops = 2.0 * q * op.n * (K * C_row) * g_ch
+        x3 = op.n * q >= 8192 and C_row * K >= 64
+        peak = MFMA_BF16_PEAK_TFLOPS / 6 if x3 else MFMA_F32_PEAK_TFLOPS
+        ach = flops / (mean_ms * 1e-3) / 1e12
+        entry["roofline"] = dict(bound="mfma", kernel="project_x3v2_kernel (bf16x3)" if x3 else "project_kernel (fp32 mfma)", achieved=round(ach, 1), peak=round(peak, 1), unit="TFLOP/s",
+                                 frac=round(ach / peak, 4), traffic=None, flops_per_step=int(flops), projection_ms_per_step=round(mean_ms, 4),
+                                 note=("fp32-equivalent flops of the (K C_in H) x C_out contraction; peak = dense bf16 matrix peak / 6 -- every fp32 product is six bf16 "
+                                       "MFMAs after the three-way operand split (DESIGN.md 3.2)") if x3 else "exact fp32 MFMA")
+    elif dom == 0:
+        n_l = len(by_kind[0]) // steps
+        mean_ms = float(np.mean(by_kind[0]))
+        ach = bytes_recursion / n_l / (mean_ms * 1e-3) / 1e9
+        entry["roofline"] = dict(bound="hbm", kernel="hop_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
+                                 algorithmic_bytes_per_launch=int(bytes_recursion / n_l), launches_per_step=n_l, mean_launch_ms=round(mean_ms, 4))
+    if 0 in by_kind and dom != 0:
+        n_l = len(by_kind[0]) // steps
+        mean_ms = float(np.mean(by_kind[0]))
+        entry["hop_roofline"] = dict(bound="hbm", achieved=round(bytes_recursion / n_l / (mean_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                     frac=round(bytes_recursion / n_l / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), launches_per_step=n_l, mean_launch_ms=round(mean_ms, 4),
+                                     path="project-first (hops on C_out-wide rows)" if pf else "hops-first")
+    ref_out, cpu = cpu_baseline(op, spec, layer, x, samples=range(q))
+    err = float(np.abs(out.cpu().numpy() - ref_out).max() / np.abs(ref_out).max())
+    entry["gpu_vs_cpu_rel_err"] = err
+    entry["cpu_baseline"] = dict(value=round(cpu["value"], 4), unit=cpu["unit"], cores=cpu["cores"], kind="port", sample=cpu["sample"])
+    assert err <= 1e-5, "%s: GPU result differs from the CPU restatement: %g" % (name, err)
+    if op.n <= 4096 and spec["cls"] in ("GCNCheb", "TGCNCheb_H"):
+        ref2, td = torch_dense_baseline(op, spec, layer, x, seconds=1.0)
+        err2 = float(np.abs(out.cpu().numpy() - ref2).max() / np.abs(ref2).max())
+        entry["torch_dense_einsum"] = dict(value=round(td["value"], 4), unit=td["unit"], cores=td["cores"], sample=td["sample"], gpu_vs_cpu_rel_err=err2)
+        assert err2 <= 1e-5, "%s: GPU result differs from the dense-L einsum restatement: %g" % (name, err2)
+    entry["seconds_in_bench"] = round(time.perf_counter() - t_start, 1)
+    del layer, x, out, op
+    torch.cuda.empty_cache()
+    return entry
 
 
 # ---- rehearsal compute (tests only): `--rehearsal-cpu` runs this file's N > 1 control flow (rendezvous, time sharding, extras,
 # watchdog, the one JSON line) with the gloo backend on the CPU, the HIP calls replaced by scipy / numpy stand-ins that are
 # injected through the hooks tgcn_amd/dist.py has for exactly this.  Nothing measured in this mode is a result (`data` says so);
 # tests/test_bench_rehearsal.py drives it at world 2 under `pytest -m "not gpu"`.
-class _CpuOperand:
-    def __init__(self, n_rows, n_cols, row, col, val, device):
-        import scipy.sparse as sp
-        self.n, self.n_cols, self.nnz = n_rows, n_cols, int(row.numel())
-        self.L = sp.coo_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n_rows, n_cols)).tocsr()
-
-
-def _cpu_hop(op, x, z, alpha, beta, out):
-    y = np.stack([op.L.dot(x[b].numpy()) for b in range(x.shape[0])]).astype(np.float32)
-    y = alpha * y + (beta * z.numpy() if z is not None else 0)
-    return out.copy_(torch.from_numpy(y.astype(np.float32)))
-
-
-def _cpu_project(terms, W, bias, bias_kind, n_vertices):
-    acc = sum(t.numpy() @ W[k].numpy() for k, t in enumerate(terms))
-    if bias_kind:
-        acc = acc + bias.numpy()
-    return torch.from_numpy(acc.astype(np.float32))
-
-
-def _cpu_pack(src, idx, out):
-    return out.copy_(src.index_select(0, idx))
-
-
 class _CpuLayer:
     """reference_power layer on the CPU (tgcn/nn/gcn.py:66-78 + :39): stands in for the HIP module in rehearsals"""
     def __init__(self, op, spec):
@@ -286,33 +359,43 @@ class _CpuLayer:
 
 
 def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, rehearsal=False, exchange="auto"):
-    """The vertex-sharded layer of SURVEY.md 8(e) on the same workload: every rank holds the seeded graph, owns an nnz-balanced
-    row range (inside its group of `vertex_shards` ranks for mode "hybrid"; the groups split the q_total time steps, no
-    communication between them) and its slice of x / bias.  -> (callable(overlap), VertexShardedCheb, groups, time steps of this group)"""
-    import tgcn_amd
-    from tgcn_amd import functional as _F
-    from tgcn_amd.dist import VertexShardedCheb, hybrid_groups, shard_time_steps
+    """The vertex-sharded layer of SURVEY.md 8(e) on the same workload through its MODULE surface (tgcn_amd.dist.ShardedTGCNCheb /
+    ShardedTGCNCheb_H: the reference's constructor arguments + a process group; weight fold, project-first and the exchange inside): every
+    rank holds the seeded graph, owns an nnz-balanced row range (inside its group of `vertex_shards` ranks for mode "hybrid"; the groups
+    split the q_total time steps, no communication between them) and its slice of x.
+    -> (callable(overlap, qs), VertexShardedCheb, groups, time steps of this group, the module)"""
+    from tgcn_amd import dist as tdist
     assert spec["cls"] in ("TGCNCheb", "TGCNCheb_H"), "vertex sharding bench is wired for the cfg5 / cfg4 layers"
     group, gi, ngroups = None, 0, 1
     if mode == "hybrid":
-        group, gi, ngroups = hybrid_groups(world, vertex_shards)
-    sl = shard_time_steps(q_total, gi, ngroups)
+        group, gi, ngroups = tdist.hybrid_groups(world, vertex_shards)
+    sl = tdist.shard_time_steps(q_total, gi, ngroups)
     q = sl.stop - sl.start
     row, col, val = op.coo()
-    hooks = dict(make_operand=_CpuOperand, hop_fn=_cpu_hop, project_fn=_cpu_project, pack_fn=_cpu_pack) if rehearsal else {}
-    sh = VertexShardedCheb(op.n, row, col, val, group=group, device=device, exchange=exchange, **hooks)
-    del row, col, val
-    K = spec["K"]
+    ops = None
+    if rehearsal:
+        from tools.cpu_standins import CpuOps
+        ops = CpuOps()
     torch.manual_seed(1)
-    C_in = spec["H"] * spec["f"]                       # TGCNCheb_H: the H time steps of a window are the row
-    Wraw = torch.empty(K, C_in, spec["g"], device=device)
-    tgcn_amd.uniform(C_in * K, Wraw)
-    Wf = Wraw if (K <= 2 or rehearsal) else _F.fold_weight(_F.power_fold_matrix(K, device), Wraw)
-    bias_local = torch.zeros(sh.owned, spec["g"], device=device)
+    graph = tdist.CooGraph(op.n, row, col, val)
+    if spec["cls"] == "TGCNCheb":
+        layer = tdist.ShardedTGCNCheb(graph, spec["f"], spec["g"], spec["K"], group=group, exchange=exchange, ops=ops)
+    else:
+        layer = tdist.ShardedTGCNCheb_H(graph, spec["f"], spec["g"], spec["K"], spec["H"], group=group, exchange=exchange, ops=ops)
+    layer = layer.to(device)
+    layer.force_sharded = True                     # also on one rank under a launcher: the exchange path meets the backend
+    sh = layer.shard(device)                       # collective: partition, halo lists (tensor collectives), operands; parameters from the group's first rank
+    layer.L = tdist.CooGraph(op.n, row[:0], col[:0], val[:0])      # the shard holds its rows: drop this rank's copy of the global entry list
+    del row, col, val, graph
+    C_in = spec["H"] * spec["f"]
     g = torch.Generator(device=device).manual_seed(rank)
     x_local = torch.randn((max(q, 1), sh.owned, C_in), device=device, generator=g)[:q]
-    # qs: only the first qs of the group's time steps (the extras size themselves to their budget; columns are independent)
-    return (lambda overlap=True, qs=None: sh.forward(x_local if qs is None else x_local[:qs], Wf, bias_local, 2, 0, overlap=overlap)), sh, ngroups, q
+
+    def fwd(overlap=True, qs=None):
+        # qs: only the first qs of the group's time steps (the extras size themselves to their budget; columns are independent)
+        layer.overlap = overlap
+        return layer(x_local if qs is None else x_local[:qs])
+    return fwd, sh, ngroups, q, layer
 
 
 class Progress:
@@ -383,7 +466,7 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
     for mi, (mode, vs) in enumerate(modes):
         try:
             progress.enter("%s: building shards" % mode)
-            fwd, sh, ngroups, qg = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs, rehearsal, args.extras_exchange)
+            fwd, sh, ngroups, qg, _ = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs, rehearsal, args.extras_exchange)
         except Exception as e:      # noqa: BLE001 -- reported, never fatal
             import traceback
             traceback.print_exc()
@@ -441,12 +524,11 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
                 progress.in_collective_since = time.perf_counter()
                 dist.all_gather_object(per_rank, mine)
                 progress.in_collective_since = None
-                C_in = spec["H"] * spec["f"]
                 # the groups of a hybrid grid run side by side: together they cover ngroups * qs time steps per forward
                 entry.update(value=round(op.nnz * (K - 1) * (qs * ngroups) * H * steps / dt / 1e9, 3), unit="G edge·timesteps/s", ms_per_step=round(dt / steps * 1e3, 3),
                              steps=steps, scaling="strong", exchange=sh.exchange, groups=ngroups, time_steps_per_group=qg, time_steps_used=qs,
                              one_time_step_ms=round(t1 * 1e3, 3),
-                             message_bytes_per_hop_and_time_step_rank0=mine["bytes_per_channel_in"] * C_in, ranks=per_rank)
+                             hop_row_floats=mine["row_floats"], message_bytes_per_hop_and_time_step_rank0=mine["bytes_in_per_hop_and_time_step"], ranks=per_rank)
             except Exception as e:      # noqa: BLE001 -- reported, never fatal
                 import traceback
                 traceback.print_exc()
@@ -461,17 +543,41 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
     return out
 
 
+def count_gpus_without_runtime():
+    """GPUs this process may use, without a HIP call: the agents of /sys/class/kfd/kfd/topology/nodes with SIMDs, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them is set.  0 where the driver's topology directory does
+    not exist (no amdgpu compute driver), None when it exists but cannot be parsed."""
+    import glob
+    n = 0
+    if not os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        return 0                                   # no amdgpu compute driver on this host: no GPU a ROCm process could open
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    try:
+        for path in files:
+            props = dict(ln.split()[:2] for ln in open(path) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: this process becomes the parent of
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` -- a CHILD process, never an exec -- and
     returns its exit code; the ranks inherit stdout / stderr, so rank 0's ONE JSON line is this command's output.  Nothing here touches
-    the GPU: torch.cuda.device_count() only counts devices (it does not initialise the runtime), and a rank count the node cannot hold is
-    refused before anything starts instead of being run on fewer GPUs."""
+    the GPU: the devices are counted from the kernel driver's topology files (count_gpus_without_runtime: no HIP call -- torch.cuda.device_count()
+    can fall back to hipGetDeviceCount, which initialises the runtime in this parent), and a rank count the node cannot hold is refused before
+    anything starts instead of being run on fewer GPUs; where the count cannot be read the ranks themselves fail on set_device."""
     import socket
     import subprocess
     if not args.rehearsal_cpu:
-        have = torch.cuda.device_count()
-        if args.gpus > have:
+        have = count_gpus_without_runtime()
+        if have is not None and args.gpus > have:
             print("bench.py: --gpus %d but this node has %d GPU(s); refusing to run the scaling bench on fewer devices" % (args.gpus, have), file=sys.stderr)
             return 2
     s = socket.socket()
@@ -510,6 +616,8 @@ def main():
     ap.add_argument("--vertices", type=int, default=None, help="override vertex count (cfg5 only; reported in config)")
     ap.add_argument("--entries", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of CPU-baseline time on the headline workload: time steps are timed two at a time until this is used up (all 16 when it allows); the rest is scaled and said so")
+    ap.add_argument("--no-others", action="store_true", help="default run (cfg5, 1 GPU): skip `other_workloads` (cfg2 f=1 / f=64, cfg3, cfg4 measured after the headline)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip roofline.gather_ceiling_ms (one extra operand build + 4 hop launches after the timed steps)")
     ap.add_argument("--shard", default="time", choices=["time", "vertex", "hybrid"], help="N > 1: time steps split over the ranks (no collective); vertex rows per rank with a halo / all-gather exchange per hop; hybrid: --vertex-shards ranks share a graph, groups split the time steps")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1, time sharding: strong = the workload's q time steps split over the ranks (default); weak = q time steps per rank")
@@ -575,11 +683,11 @@ def main():
     vertex_mode = dist is not None and args.shard in ("vertex", "hybrid")       # world 1 under a launcher: the same code on one rank (first contact with RCCL)
     ngroups = 1
     if vertex_mode:
-        fwd, sh, ngroups, q = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards, rehearsal, args.extras_exchange)
+        fwd, sh, ngroups, q, sharded_module = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards, rehearsal, args.extras_exchange)
         spec["q"] = q
 
         class _Sharded:
-            bias = None
+            bias = sharded_module.bias
             def __call__(self, _x):
                 return fwd()
         layer, x = _Sharded(), None
@@ -642,13 +750,17 @@ def main():
     fix_ms = [ms for kind, ms in prof if kind == 1]
     C_row = H * spec["f"]
     F = q * C_row
-    pf_path = (not vertex_mode) and hop_ms and _F.use_project_first(q, op.n, C_row, spec["g"]) and not _F.small_path_tile(op, C_row, 0)
+    if vertex_mode:
+        pf_path = bool(hop_ms) and sh.use_project_first(C_row, spec["g"], K)
+    else:
+        pf_path = hop_ms and _F.use_project_first(q, op.n, C_row, spec["g"]) and not _F.small_path_tile(op, C_row, 0)
     if pf_path:
         F = q * spec["g"]      # project-first: the hops run on the (q, n, C_out) results, not on the C_in*H-wide inputs
     nnz_l, n_l = (sh.op.nnz, sh.owned) if vertex_mode else (op.nnz, op.n)      # what ONE rank's launches process
     bytes_recursion = (K - 1) * (8 * nnz_l + 4 * (n_l + 1) + 8 * n_l * F)
     n_hop_launches = (len(hop_ms) + len(hop_long_ms)) // args.steps if hop_ms else 0      # hops of one forward, fused or not
     roofline = None
+    plan_r = None
     small_ms = [ms for kind, ms in prof if kind == 4]
     if small_ms and not hop_ms:
         # one-launch LDS-resident path: the whole layer is one kernel; algorithmic bytes = SURVEY 8(d) whole-layer figure
@@ -736,6 +848,23 @@ def main():
         ref_out, cpu = cpu_baseline(op, spec, layer, x, samples=check)
         got = np.stack([out[i].cpu().numpy() for i in check])
         errs = [float(np.abs(got[i] - ref_out[i]).max() / np.abs(ref_out[i]).max()) for i in range(len(check))]
+        # more time steps, two at a time, while --cpu-budget lasts ("executed per time-step chunk and summed"); every one is also a parity check
+        timed, spent, units_done = list(check), cpu["seconds"], cpu["value"] * 1e9 * cpu["seconds"]
+        rest = [i for i in range(q) if i not in check]
+        while rest and spent + 1.15 * (spent / len(timed)) * min(2, len(rest)) <= args.cpu_budget:
+            chunk, rest = rest[:2], rest[2:]
+            ref_c, c2 = cpu_baseline(op, spec, layer, x, samples=chunk)
+            errs += [float(np.abs(out[i].cpu().numpy() - ref_c[j]).max() / np.abs(ref_c[j]).max()) for j, i in enumerate(chunk)]
+            timed += chunk
+            spent += c2["seconds"]
+            units_done += c2["value"] * 1e9 * c2["seconds"]
+            del ref_c
+        cpu.update(value=units_done / spent / 1e9, seconds=round(spent, 2), samples_timed=sorted(timed),
+                   scaled_from=None if len(timed) == q else "%d/%d" % (len(timed), q),
+                   sample="time steps %s of the %d of the same workload (two per call, summed), full K=%d forward, oracle/cheb_ref.c OpenMP, %.1f s%s"
+                          % (sorted(timed), q, K, spent, "" if len(timed) == q else "; the rate is per time step, so the other %d scale 1:1 (--cpu-budget %.0f s)" % (q - len(timed), args.cpu_budget)))
+        cpu["host"] = host_description()
+        check = sorted(timed)
         err = max(errs)
         cpu["gpu_vs_cpu_rel_err"] = err
         cpu["checked_samples"] = check
@@ -804,6 +933,21 @@ def main():
             line["other_shardings"] = extras
             print(json.dumps(line), flush=True)
     elif rank == 0:
+        if world == 1 and dist is None and args.workload == "cfg5" and not args.no_others and not rehearsal and args.vertices is None and args.entries is None:
+            # the driver's one command measures BASELINE.json's other configurations too, after the headline and with
+            # everything of the headline freed; the headline's fields above are final at this point.  A failure here is reported, never fatal.
+            del out, x, layer, op
+            plan = plan_r = None
+            torch.cuda.empty_cache()
+            others = []
+            for name in ("cfg2", "cfg2w", "cfg3", "cfg4"):
+                try:
+                    others.append(other_workload_entry(name, device))
+                except Exception as e:      # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    others.append(dict(config=name, error="%s: %s" % (type(e).__name__, str(e)[:300])))
+            line["other_workloads"] = others
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

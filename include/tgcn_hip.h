@@ -30,7 +30,7 @@ extern "C" {
 #define TGCN_ERR_WORKSPACE (-3)   /* caller workspace too small */
 #define TGCN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
 
-#define TGCN_ABI_VERSION 6
+#define TGCN_ABI_VERSION 7
 
 /* One stored entry of the sparse operand: 8 bytes, read with a single load. */
 typedef struct tgcn_edge {
@@ -168,9 +168,10 @@ int tgcn_graclus_match_f64(int64_t nnz, const int64_t* rr, const int64_t* cc, co
 const tgcn_csr_sched* tgcn_sched_get(const tgcn_sched* s);
 void tgcn_sched_destroy(tgcn_sched* s);
 
-/* Optional launch timing for benchmarks: between start and stop every kernel launch made through this
- * library is bracketed by a hipEvent pair on its own stream.  stop() synchronises those events and returns
- * (kind, milliseconds) per launch in launch order.  Not for use under hipGraph capture. */
+/* Optional launch timing for benchmarks: between start and stop every kernel launch THE CALLING THREAD makes through this
+ * library is bracketed by a hipEvent pair on its own stream.  stop() (same thread) synchronises those events and returns
+ * (kind, milliseconds) per launch in launch order.  Thread-local since ABI v7: launches of other threads (DataParallel replicas,
+ * autograd workers running a backward) are not recorded and never touch the record.  Not for use under hipGraph capture. */
 #define TGCN_PROF_HOP 0
 #define TGCN_PROF_HOP_FIXUP 1
 #define TGCN_PROF_PROJECT 2
@@ -184,7 +185,11 @@ int tgcn_profile_start(int32_t capacity);
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count);
 
 /* Developer switches for A/B runs (tools/hop_bench.py, tools/proj_bench.py; every one is checked against the oracle in
- * tests/test_fuzz_parity.py).  Process-wide, same arithmetic, another kernel; returns TGCN_ERR_INVALID for unknown keys.
+ * tests/test_fuzz_parity.py).  State of the CALLING THREAD since ABI v7 (thread_local in the library, as is the launch-timing record of
+ * tgcn_profile_*): a switch changes the launches the calling thread issues afterwards and nothing else -- the threads of an
+ * nn.DataParallel process (examples/pytorch_based/pytorch_hcp_tgcn.py:270-273) and the autograd engine's workers keep the defaults,
+ * which are what ships; the library holds no process-global mutable state, only caches of immutable per-device facts
+ * (CU count, the LDS attribute of a kernel, one helper stream per device).  Same arithmetic, another kernel; TGCN_ERR_INVALID for unknown keys.
  *   "hop_variant"     0 shipped hop kernel; 1.. alternative unroll / row-interleave shapes of hop.h
  *   "hop_xcd_remap"   1 (default): each XCD gets a contiguous range of row blocks; 0: row blocks round robin over the XCDs
  *   "hop_seg_remap"   1: each XCD gets a contiguous range of the column-ordered segment blocks; 0 (default): round robin
@@ -205,7 +210,7 @@ int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* coun
  *                     fp32 MFMA only, 0 vector-ALU one-launch kernels
  *   "small_narrow"    0: C <= 4 inputs use the output-side one-launch kernel (default 1: input-side recursion) */
 int tgcn_set_tuning(const char* key, int32_t value);
-/* Every switch above back to its default (ABI v5).  The switches are process-global developer state: a harness that sets one restores
+/* Every switch above back to its default, for the calling thread (ABI v5; thread-local since v7).  A harness that sets one restores
  * them with this call in its teardown, whatever happened in between (tests/conftest.py does after every test). */
 void tgcn_reset_tuning(void);
 
@@ -362,6 +367,15 @@ size_t tgcn_cheb_forward_pf_workspace_bytes(const tgcn_csr_sched* sched, int32_t
 int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sched* sched, int32_t mode, int32_t K, int64_t q,
                              int64_t n, int32_t C, int32_t N, const float* x, const float* Wcat, const float* bias,
                              int32_t bias_kind, float* out, void* workspace, size_t workspace_bytes);
+
+/* The first step of that form on its own (ABI v7): Z[b, r(m), 0:K*N] = x[b, m, 0:C] . Wcat, bias added to the first N columns (Z_0).
+ * x: (q, rows, C) contiguous; Z: (q, rows, K*N) contiguous; bias: [N] (kind 1) or [rows, N] (kind 2), read at the OUTPUT row.
+ * rowmap (nullable, device, int32[rows]): output row r(m) = rowmap[m] -- a vertex shard keeps its rows in the order
+ * [interior | boundary] and writes Z in that order while reading x in the caller's.  The caller then runs the Horner / Clenshaw
+ * recursion itself with tgcn_csr_hop2_f32 on strided views of Z: the vertex-sharded layer exchanges the cut rows of every
+ * intermediate result between its hops (tgcn_amd/dist.py; reference call shape examples/pytorch_based/pytorch_hcp_tgcn.py:103-104). */
+int tgcn_cheb_project_first_f32(void* stream, int64_t q, int64_t rows, int32_t C, int32_t K, int32_t N, const float* x, const float* Wcat,
+                                const float* bias, int32_t bias_kind, const int32_t* rowmap, float* Z);
 
 /* Small graphs (n <= 1024, C <= 128, CSR + activations fit in 160 KB of LDS -- the reference's own MNIST / coarsened
  * graphs): the whole layer in ONE launch, recursion run on the output side in LDS (Horner for mode 0, Clenshaw for

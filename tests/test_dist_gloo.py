@@ -10,6 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import cheb_oracle as O
+from tools.cpu_standins import CpuOps       # numpy / scipy stand-ins for the HIP calls (test infrastructure)
 
 
 def _free_port():
@@ -35,33 +36,6 @@ def _graph(n, seed, banded):
     return row, col, val
 
 
-class _ScipyOperand:
-    def __init__(self, n_rows, n_cols, row, col, val, device):
-        import scipy.sparse as sp
-        self.n, self.n_cols = n_rows, n_cols
-        self.L = sp.coo_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n_rows, n_cols)).tocsr()
-
-
-def _hop(op, x, z, alpha, beta, out):
-    y = np.stack([op.L.dot(x[b].numpy()) for b in range(x.shape[0])]).astype(np.float32)
-    y = alpha * y + (beta * z.numpy() if z is not None else 0)
-    out.copy_(torch.from_numpy(y.astype(np.float32)))
-    return out
-
-
-def _pack(src, idx, out):
-    return out.copy_(src.index_select(0, idx))
-
-
-def _project(terms, W, bias, bias_kind, n_vertices):
-    acc = sum(t.numpy().astype(np.float64) @ W[k].numpy().astype(np.float64) for k, t in enumerate(terms))
-    if bias_kind == 1:
-        acc = acc + bias.numpy()
-    elif bias_kind == 2:
-        acc = (acc.reshape(-1, n_vertices, acc.shape[-1]) + bias.numpy()).reshape(acc.shape)
-    return torch.from_numpy(acc.astype(np.float32))
-
-
 def _worker(rank, world, port, exchange, banded, mode, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,7 +48,7 @@ def _worker(rank, world, port, exchange, banded, mode, ret):
         W = (rng.standard_normal((K, C, N)) / 4).astype(np.float32)
         bias = rng.standard_normal((n, N)).astype(np.float32)
         sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), device="cpu",
-                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project, pack_fn=_pack)
+                               exchange=exchange, ops=CpuOps())
         args = (torch.from_numpy(x[:, sh.lo:sh.hi]), torch.from_numpy(W), torch.from_numpy(bias[sh.lo:sh.hi]), 2, mode)
         out_local = sh.forward(*args)                              # overlapped: interior rows / other time steps under the exchange
         plain = sh.forward(*args, overlap=False)                   # one exchange, then one hop on all owned rows
@@ -132,7 +106,7 @@ def _hybrid_worker(rank, world, port, exchange, banded, ret):
         group, gi, ng = hybrid_groups(world, 2)
         sl = shard_time_steps(q, gi, ng)                       # this group's samples
         sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), group=group, device="cpu",
-                               exchange=exchange, make_operand=_ScipyOperand, hop_fn=_hop, project_fn=_project, pack_fn=_pack)
+                               exchange=exchange, ops=CpuOps())
         out_local = sh.forward(torch.from_numpy(x[sl, sh.lo:sh.hi]), torch.from_numpy(W), torch.from_numpy(bias), 1, 1)
         assert torch.equal(out_local, sh.forward(torch.from_numpy(x[sl, sh.lo:sh.hi]), torch.from_numpy(W), torch.from_numpy(bias), 1, 1, overlap=False))
         L = O.coo_to_csr(row, col, val, n)

@@ -746,6 +746,35 @@ def test_operand_cache_does_not_go_stale(gpu_device):
         assert rel_err(out.detach().cpu().numpy(), ref) <= TOL, it
 
 
+def test_in_place_edit_in_the_middle_of_a_scipy_operand_is_seen(gpu_device):
+    """L.data edited in place somewhere in the middle (gcn/graph.py:236 does for lmax != 2) -- the numpy twin and a module
+    holding the scipy matrix must compute with the NEW values (the round-5 key looked at the first and last 32 values only)"""
+    import scipy.sparse as sp
+    import tgcn_amd
+    from tgcn_amd import numpy_api
+    rng = np.random.default_rng(31)
+    n, K = 500, 4
+    for dtype in (np.float32, np.float64):
+        L = sp.random(n, n, 0.02, format="csr", dtype=dtype, random_state=5)
+        X = rng.standard_normal((n, 6)).astype(dtype)
+        first = numpy_api.chebyshev(L, X, K)
+        assert rel_err(first, O.graph_chebyshev(L, X, K)) <= (TOL if dtype == np.float32 else 1e-12)
+        mid = slice(L.nnz // 2 - 40, L.nnz // 2 + 40)
+        L.data[mid] *= -3.0                                   # same object, same address, first and last values untouched
+        want = O.graph_chebyshev(L, X, K)
+        got = numpy_api.chebyshev(L, X, K)
+        assert rel_err(got, want) <= (TOL if dtype == np.float32 else 1e-12)
+        assert rel_err(first, want) > 1e-3                    # ... and the edit does matter
+    L = sp.random(n, n, 0.02, format="csr", dtype=np.float32, random_state=6)
+    torch.manual_seed(0)
+    layer = tgcn_amd.GCNCheb(L, 2, 5, K).cuda()
+    x = rng.standard_normal((3, n, 2)).astype(np.float32)
+    W, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+    assert rel_err(layer(_dev(x)).detach().cpu().numpy(), O.gcn_cheb_forward(L, x, W, b)) <= TOL
+    L.data[L.nnz // 2 - 40: L.nnz // 2 + 40] *= -3.0
+    assert rel_err(layer(_dev(x)).detach().cpu().numpy(), O.gcn_cheb_forward(L, x, W, b)) <= TOL
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_backward_large_sparse_vs_scipy(mode, gpu_device):
     """General-path backward at a size where the transposed operand has multi-segment and > 64-segment rows, the weight

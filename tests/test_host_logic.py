@@ -138,7 +138,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib().tgcn_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().tgcn_abi_version() == _lib.ABI_VERSION == 7
 
 
 def _kernel_resources():
@@ -380,6 +380,52 @@ def test_operand_cache_evicts_least_recently_used_only():
     assert built == list(range(17)) + [1] and 2 not in cache._d
 
 
+def test_scipy_and_ndarray_operands_are_keyed_by_their_whole_content():
+    """a scipy / ndarray L has no version counter; the cache key is a hash of ALL of data (+ indices, indptr), so an
+    in-place edit anywhere -- gcn/graph.py:236 rescales L.data in place for lmax != 2, examples/gcn_mnist.py:131 rebuilds L between calls --
+    is a new key.  (Round 5 tagged the first and last 32 values only.)  The numpy_api cache is LRU and locked like the modules' own."""
+    import threading
+    import scipy.sparse as sp
+    from tgcn_amd import numpy_api
+    from tgcn_amd.nn import _np_fingerprint
+    rng = np.random.default_rng(3)
+    L = sp.random(400, 400, 0.05, format="csr", dtype=np.float32, random_state=3)
+    assert L.nnz > 200
+    base = _np_fingerprint(L)
+    assert base == _np_fingerprint(L) == numpy_api._fingerprint(L)
+    L.data[L.nnz // 2] *= 1.5                                   # an edit in the MIDDLE of the stored values
+    mid = _np_fingerprint(L)
+    assert mid != base
+    L.indices[L.nnz // 2], L.indices[L.nnz // 2 - 1] = L.indices[L.nnz // 2 - 1], L.indices[L.nnz // 2]      # the pattern counts too
+    assert _np_fingerprint(L) != mid
+    for fmt in ("coo", "csc"):
+        M = L.asformat(fmt)
+        a = _np_fingerprint(M)
+        M.data[M.nnz // 3] += 1.0
+        assert _np_fingerprint(M) != a
+    D = rng.standard_normal((50, 50))
+    a = _np_fingerprint(D)
+    D[25, 25] += 1.0
+    assert _np_fingerprint(D) != a
+    # LRU + lock
+    cache = numpy_api._LruCache(max_entries=3)
+    built = []
+    for k in range(3):
+        cache.get(k, lambda k=k: built.append(k) or k)
+    cache.get(0, lambda: built.append("again"))                 # hit: most recent
+    cache.get(3, lambda: built.append(3) or 3)                  # evicts 1 only
+    assert built == [0, 1, 2, 3] and list(cache._d) == [2, 0, 3]
+    barrier, got = threading.Barrier(6), [None] * 6
+
+    def worker(i):
+        barrier.wait()
+        got[i] = cache.get("shared", object)
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(g is got[0] for g in got)
+
+
 def test_learnable_operand_values_are_never_silently_ignored():
     """Reference: lap = -deg[row] * edge_weight * deg[col] and spmm's `value` are differentiable (tgcn/nn/gcn.py:413,510,296-308).  The MODULES
     and spmm* carry that gradient (tests/test_values_grad.py, GPU); the low-level operand builder, which packs values outside autograd,
@@ -529,3 +575,29 @@ def test_hub_first_reordering_warns_and_spreads_the_hot_block():
     assert torch.equal(_spread_hot_block(torch.arange(16), 64), torch.tensor([0, 4, 2, 6, 1, 5, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15]))
     with pytest.raises(Exception, match="unknown order"):
         op.reordered("random")
+
+
+def test_hot_kernels_do_not_spill():
+    """project_x3_stream_kernel runs 1024-thread workgroups at exactly 128 VGPRs with up to 150 KB of dynamic LDS; a compiler update
+    that makes it (or the hop kernel) spill would show up only as a slower bench.  The gfx950 code object's own metadata says what the BUILT
+    library uses (tools/kernel_resources.py): the hop kernel of the headline and the wide bf16x3 projection must be spill-free, the streaming
+    projection may keep the four loop-invariant VGPRs it parks in scratch before its tile loop today (<4, 2>: 20 bytes, stored and loaded
+    once per wave, outside the loop) and nothing more."""
+    import shutil
+    from tgcn_amd import _lib
+    from tools import kernel_resources as kr
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(os.path.join(kr.LLVM, "llvm-readelf")):
+        pytest.skip("needs the built library and llvm-readelf")
+    res = kr.kernel_resources(_lib.LIB_PATH)
+    assert len(res) > 200
+    by = lambda frag: {k: v for k, v in res.items() if frag in k}          # noqa: E731 -- mangled names
+    hop = by("10hop_kernelILi16ELi4ELi8ELi1E")
+    stream = by("24project_x3_stream_kernel")
+    wide = by("19project_x3v2_kernel")
+    assert len(hop) >= 4 and len(stream) == 6 and len(wide) >= 5
+    for name, r in list(hop.items()) + list(wide.items()):
+        assert r["vgpr_spill_count"] == 0 and r["sgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+    for name, r in stream.items():
+        assert r["vgpr_count"] <= 128, (name, r)                              # 1024 threads per workgroup: 4 waves per SIMD
+        assert r["vgpr_spill_count"] <= 4 and r["private_segment_fixed_size"] <= 20 and r["uses_dynamic_stack"] in ("false", 0), (name, r)
+    assert shutil.which("true")

@@ -15,13 +15,56 @@ def _dev(a):
     return torch.as_tensor(a).cuda()
 
 
-@pytest.mark.parametrize("K,C,N", [(5, 64, 64), (1, 7, 3), (25, 15, 32), (3, 1200, 32)])
+@pytest.mark.parametrize("K,C,N", [(5, 64, 64), (1, 7, 3), (25, 15, 32), (3, 1200, 32),
+                                   (25, 1536, 64), (11, 1200, 160)])      # the last two: K*C*N > 2^21 elements, beyond one pass of the capped grid
 def test_weight_layouts_equal_torch_permutes(K, C, N, gpu_device):
     from tgcn_amd import functional as F
     W = torch.randn(K, C, N, device="cuda")
     assert torch.equal(F.weight_layout(W, 0), W.permute(1, 0, 2).reshape(C, K * N))
     assert torch.equal(F.weight_layout(W, 1), W.permute(0, 2, 1).contiguous())
     assert torch.equal(F.weight_layout(W, 2), W.permute(2, 0, 1).reshape(N, K * C))
+
+
+@pytest.mark.parametrize("K,CN", [(5, 4096), (25, 1536 * 64), (3, (1 << 21) + 77)])      # CN beyond 8192 workgroups x 256 threads: grid-stride
+def test_fold_weight_beyond_one_grid_pass(K, CN, gpu_device):
+    from tgcn_amd import functional as F
+    torch.manual_seed(K)
+    W = torch.randn(K, CN, 1, device="cuda")
+    fold = F.power_fold_matrix(K, W.device)
+    for transpose in (False, True):
+        got = F.fold_weight(fold, W, transpose=transpose)
+        m = fold.double().t() if not transpose else fold.double()
+        want = (m @ W.double().view(K, CN)).view(K, CN, 1)
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 2e-6
+
+
+def test_layer_with_a_weight_beyond_one_grid_pass(gpu_device):
+    """K*C*N = 11 * 1200 * 160 > 2^21: the project-first forward (weight layout kind 0) and the input gradient (kinds 1 / 2) against float64"""
+    import tgcn_amd
+    rng = np.random.default_rng(5)
+    n, K, H, g = 300, 11, 1200, 160
+    ei = rng.integers(0, n, (2, 2400))
+    A = np.zeros((n, n), np.float32)
+    A[ei[0], ei[1]] = (rng.standard_normal(2400) / 6).astype(np.float32)
+    L = torch.as_tensor(A).cuda()
+    torch.manual_seed(2)
+    layer = tgcn_amd.TGCNCheb_H(L, 1, g, K, H).cuda()
+    x = torch.randn(2, n, H, device="cuda", requires_grad=True)
+    out = layer(x)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    xd = x.detach().double().requires_grad_(True)
+    Wd = layer.weight.detach().double().reshape(K, H, g).requires_grad_(True)
+    Ld = L.double()
+    Xt, P = [xd], xd
+    for k in range(1, K):
+        P = torch.einsum("nm,qmc->qnc", Ld, P)
+        Xt.append(P if k == 1 else 2 * P - Xt[k - 2])
+    ref = sum(Xt[k] @ Wd[k] for k in range(K)) + layer.bias.detach().double()
+    ref.backward(gout.double())
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-5
+    assert rel_err(x.grad.cpu().numpy(), xd.grad.cpu().numpy()) <= 2e-5
+    assert rel_err(layer.weight.grad.reshape(K, H, g).cpu().numpy(), Wd.grad.cpu().numpy()) <= 2e-5
 
 
 @pytest.mark.parametrize("q,n,C", [(3, 1000, 64), (2, 333, 33), (5, 70, 1200), (4, 900, 28), (1, 50, 64)])

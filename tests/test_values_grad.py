@@ -190,3 +190,60 @@ def test_spmm_with_a_learnable_value_keeps_one_operand(gpu_device):
         out.square().sum().backward()
         opt.step()
     assert len(tnn._spmm_ops._d) - before <= 2          # the operand and the entry order, however many steps
+
+
+@pytest.mark.parametrize("small", [True, False])
+def test_two_learnable_weights_on_one_pattern_backward_after_both_forwards(small, gpu_device, monkeypatch):
+    """the operand of a pattern holds ONE set of packed values, refreshed in place; a backward reads them.  Two forwards with
+    two different learnable weights on the same edge_index / index, both backwards AFTER both forwards: the first backward must differentiate the
+    first forward's operand (functional._values_guard re-packs the values saved in ctx), and a third forward afterwards packs its own weight again."""
+    import tgcn_amd
+    from tgcn_amd import functional as F
+    if not small:
+        monkeypatch.setattr(F, "SMALL_PATH", False)
+    rng = np.random.default_rng(21)
+    n, E, f, g, K = 300, 2400, 4, 5, 4
+    ei = torch.as_tensor(_edges(n, E, rng)).cuda()
+    torch.manual_seed(0)
+    layer = tgcn_amd.ChebConv(f, g, K).cuda()
+    x0 = torch.as_tensor(rng.standard_normal((2, n, f)).astype(np.float32)).cuda()
+    gout = torch.as_tensor(rng.standard_normal((2, n, g)).astype(np.float32)).cuda()
+    wa0 = torch.as_tensor(rng.uniform(0.5, 1.5, E).astype(np.float32)).cuda()
+    wb0 = torch.as_tensor(rng.uniform(0.5, 1.5, E).astype(np.float32)).cuda()
+
+    def alone(w0):                       # each weight on its own: forward, backward, nothing in between
+        w, x = w0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        layer.zero_grad()
+        out = layer(x, ei, w)
+        out.backward(gout)
+        return [t.detach().clone() for t in (out, w.grad, x.grad, layer.weight.grad)]
+    want_a, want_b = alone(wa0), alone(wb0)
+    wa, wb = wa0.clone().requires_grad_(True), wb0.clone().requires_grad_(True)
+    xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    out_a = layer(xa, ei, wa)
+    out_b = layer(xb, ei, wb)            # same pattern, other values: the operand now holds wb's
+    layer.zero_grad()
+    out_a.backward(gout)                 # ... and this backward needs wa's
+    got_a = [out_a.detach(), wa.grad, xa.grad, layer.weight.grad.clone()]
+    layer.zero_grad()
+    out_b.backward(gout)
+    got_b = [out_b.detach(), wb.grad, xb.grad, layer.weight.grad.clone()]
+    for got, want in ((got_a, want_a), (got_b, want_b)):
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    again = alone(wa0)                   # the stamp of the last packing was dropped with the re-pack: a later forward packs its own weight
+    for a, b in zip(again, want_a):
+        assert torch.equal(a, b)
+    # the same through spmm_batch_2 (module-global operand cache, one index, two value tensors)
+    idx = torch.as_tensor(rng.integers(0, n, (2, E))).cuda()
+    M = torch.as_tensor(rng.standard_normal((3, n, 6)).astype(np.float32)).cuda()
+    g2 = torch.as_tensor(rng.standard_normal((3, n, 6)).astype(np.float32)).cuda()
+    va, vb = wa0.clone().requires_grad_(True), wb0.clone().requires_grad_(True)
+    Ma, Mb = M.clone().requires_grad_(True), M.clone().requires_grad_(True)
+    oa = tgcn_amd.spmm_batch_2(idx, va, n, Ma)
+    ob = tgcn_amd.spmm_batch_2(idx, vb, n, Mb)
+    oa.backward(g2)
+    ob.backward(g2)
+    for v0, v, Mx in ((wa0, va, Ma), (wb0, vb, Mb)):
+        A = torch.zeros(n, n, dtype=torch.float64, device="cuda").index_put((idx[0], idx[1]), v0.double(), accumulate=True)
+        assert rel_err(Mx.grad.cpu().numpy(), torch.einsum("nm,qnc->qmc", A, g2.double()).cpu().numpy()) <= GRAD_TOL

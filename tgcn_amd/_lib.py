@@ -76,6 +76,7 @@ SIGNATURES = {
     "tgcn_cheb_forward_pf_workspace_bytes": (C.c_size_t, [C.POINTER(SchedStruct), C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
     "tgcn_cheb_forward_pf_f32": (C.c_int, [_P, C.POINTER(CsrStruct), C.POINTER(SchedStruct), C.c_int32, C.c_int32, C.c_int64,
                                            C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, C.c_size_t]),
+    "tgcn_cheb_project_first_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P]),
     "tgcn_cheb_project_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P),
                                         C.POINTER(C.c_int64), _P, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                         _P, C.c_int64]),
@@ -126,7 +127,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6      # include/tgcn_hip.h: TGCN_ABI_VERSION
+ABI_VERSION = 7      # include/tgcn_hip.h: TGCN_ABI_VERSION
 
 
 def source_hash():

@@ -19,19 +19,19 @@ thread_local char g_err[512] = "";
 
 constexpr int kBlock = 256;
 
-// ---- optional launch timing (bench / tests): hipEvent pairs recorded around launches on their own stream
+// ---- optional launch timing (bench / tests): hipEvent pairs recorded around launches on their own stream.
+// State of the CALLING THREAD (round 6: the ABI holds no process-global mutable state): a thread that asked for a
+// record gets the launches IT issues; the replicas' threads of an nn.DataParallel process neither see nor disturb it.
 struct ProfRec { hipEvent_t a, b; int kind; };
-std::mutex g_prof_mu;
-std::vector<ProfRec> g_prof;
-std::atomic<int> g_prof_cap{0};
+thread_local std::vector<ProfRec> g_prof;
+thread_local int g_prof_cap = 0;
 
 struct ProfScope {
   hipEvent_t b = nullptr;
   hipStream_t st;
   ProfScope(int kind, hipStream_t s) : st(s) {
-    if (g_prof_cap.load(std::memory_order_relaxed) <= 0) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if ((int)g_prof.size() >= g_prof_cap.load()) return;
+    if (g_prof_cap <= 0) return;
+    if ((int)g_prof.size() >= g_prof_cap) return;
     ProfRec r;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     r.kind = kind;
@@ -56,6 +56,22 @@ inline void allow_large_lds(const void* fn, int bytes) {
 
 // Compute units of the calling thread's current device (256 on MI355X), read once per device: round sizes of one-workgroup-per-CU
 // kernels follow from it instead of a literal.
+// Dynamic LDS a workgroup of the calling thread's current device can opt in to (163,840 B on gfx950; 65,536 on gfx942), read once per device:
+// kernels that keep a whole weight resident (project_x3_stream_kernel: up to 150 KB) are only chosen where it fits, the tiled forms otherwise.
+inline int lds_optin_limit() {
+  static std::atomic<int> cached[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 64 * 1024;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess || v <= 0) {
+    (void)hipGetLastError();
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+  }
+  cached[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
 inline int cu_count() {
   static std::atomic<int> cached[16];
   int dev = 0;
@@ -67,21 +83,29 @@ inline int cu_count() {
   return v;
 }
 
-std::atomic<int> g_hop_variant{0};
-std::atomic<int> g_hop_remap{1};        // hop_kernel: row blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)
-std::atomic<int> g_hop_seg_remap{0};    // hop_kernel: segment blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)
-std::atomic<int> g_hop_mix{0};          // hop_kernel: row blocks dealt evenly among the segment blocks (1) or all in front (0)
-std::atomic<int> g_hop_stream{1};       // hop_kernel: non-temporal entries / stores / partial rows when the output exceeds the Infinity Cache (0: never)
-std::atomic<int> g_hop_lds_pad{0};      // hop_kernel: bytes of unused dynamic LDS per workgroup (occupancy limiter, developer A/B)
-std::atomic<int> g_proj_variant{0};   // 1: force the streaming-W kernel
-std::atomic<int> g_overlap{0};
-std::atomic<int> g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS
-std::atomic<int> g_compact_proj{0};     // compacted forward: 0 two row-mapped projections (compact rows, empty rows), 1 one projection over all vertices in order
-std::atomic<int> g_fuse_last{0};        // compacted forward: 1 = last hop's short rows gathered inside the projection (project_x3_gather_kernel), bitwise the same
-                                         // result; measured SLOWER (cfg5 290 -> 329 ms: the gathers want the hop kernel's occupancy), so 0 = hop + projection ships
-std::atomic<int> g_x3_tail{1};          // project_x3v2_kernel: rows of a thinly filled last round as 128-row tiles (0: 256-row tiles throughout)
-std::atomic<int> g_small_narrow{1};    // C <= 4 inputs of the one-launch path: input-side recursion (0: output-side kernel)
-std::atomic<int> g_small_dense{2};     // small dense operands: 2 bf16x3 matrix pipe, 1 fp32 matrix pipe, 0 vector-ALU kernels only        // layer driver: projection of pass i on a side stream under the hops of pass i+1
+// ---- developer switches (tgcn_set_tuning): state of the CALLING THREAD, like the launch timing above.  A switch set by a test or a tool
+// selects another kernel for the same arithmetic in the launches that thread issues afterwards; other threads (DataParallel replicas,
+// the autograd engine's workers) keep the defaults, which are what ships.
+struct TuneInt {
+  int v;
+  int load() const { return v; }
+  void store(int x) { v = x; }
+};
+thread_local TuneInt g_hop_variant{0};
+thread_local TuneInt g_hop_remap{1};        // hop_kernel: row blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)
+thread_local TuneInt g_hop_seg_remap{0};    // hop_kernel: segment blocks in XCD-contiguous ranges (1) or round robin over the XCDs (0)
+thread_local TuneInt g_hop_mix{0};          // hop_kernel: row blocks dealt evenly among the segment blocks (1) or all in front (0)
+thread_local TuneInt g_hop_stream{1};       // hop_kernel: non-temporal entries / stores / partial rows when the output exceeds the Infinity Cache (0: never)
+thread_local TuneInt g_hop_lds_pad{0};      // hop_kernel: bytes of unused dynamic LDS per workgroup (occupancy limiter, developer A/B)
+thread_local TuneInt g_proj_variant{0};     // 1: force the streaming-W kernel
+thread_local TuneInt g_overlap{0};          // layer driver: projection of pass i on a side stream under the hops of pass i+1
+thread_local TuneInt g_x3_form{2};          // bf16x3 projection, aligned operands, >= 96 output columns: 2 = A fragments from registers (+20 %), 1 = both operands through LDS
+thread_local TuneInt g_compact_proj{0};     // compacted forward: 0 two row-mapped projections (compact rows, empty rows), 1 one projection over all vertices in order
+thread_local TuneInt g_fuse_last{0};        // compacted forward: 1 = last hop's short rows gathered inside the projection (project_x3_gather_kernel), bitwise the same
+                                            // result; measured SLOWER (cfg5 290 -> 329 ms: the gathers want the hop kernel's occupancy), so 0 = hop + projection ships
+thread_local TuneInt g_x3_tail{1};          // project_x3v2_kernel: rows of a thinly filled last round as 128-row tiles (0: 256-row tiles throughout)
+thread_local TuneInt g_small_narrow{1};     // C <= 4 inputs of the one-launch path: input-side recursion (0: output-side kernel)
+thread_local TuneInt g_small_dense{2};      // small dense operands: 2 bf16x3 matrix pipe, 1 fp32 matrix pipe, 0 vector-ALU kernels only
 
 struct SideStream { hipStream_t st = nullptr; hipEvent_t hops_done[2] = {nullptr, nullptr}; hipEvent_t proj_done[2] = {nullptr, nullptr}; };
 std::mutex g_side_mu;

@@ -199,13 +199,13 @@ __global__ __launch_bounds__(kBlock) void hop_f64_kernel(int64_t n, const int32_
 // recursion and the monomials (tgcn_amd/functional.py::power_fold_matrix) applied to a (K, CN) weight or weight gradient.
 __global__ __launch_bounds__(kBlock) void fold_weight_kernel(const float* __restrict__ fold, const float* __restrict__ W, float* __restrict__ out,
                                                              int K, int64_t CN, int transpose) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= CN) return;
-  for (int j = 0; j < K; ++j) {
-    float a = 0.f;
-    for (int k = 0; k < K; ++k) a = fmaf(transpose ? fold[j * K + k] : fold[k * K + j], W[(int64_t)k * CN + i], a);
-    out[(int64_t)j * CN + i] = a;
-  }
+  // grid-stride: grid_1d caps the grid at 8192 workgroups (2 M threads), a (K, C, N) weight can be larger (K = 25, C = H f = 1536, N = 64)
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < CN; i += (int64_t)gridDim.x * kBlock)
+    for (int j = 0; j < K; ++j) {
+      float a = 0.f;
+      for (int k = 0; k < K; ++k) a = fmaf(transpose ? fold[j * K + k] : fold[k * K + j], W[(int64_t)k * CN + i], a);
+      out[(int64_t)j * CN + i] = a;
+    }
 }
 
 // The three re-layouts of a (K, C, N) layer weight that the drivers take (tiny tensors; round 4 did them with torch permutes on the forward path):
@@ -214,14 +214,14 @@ __global__ __launch_bounds__(kBlock) void fold_weight_kernel(const float* __rest
 //   kind 2  (N, K*C)   out[n, k*C + c] = W[k, c, n]    G = g [W_0^T | ... | W_{K-1}^T] for all K terms in one projection
 __global__ __launch_bounds__(kBlock) void weight_layout_kernel(const float* __restrict__ W, float* __restrict__ out, int K, int C, int N, int kind) {
   const int64_t total = (int64_t)K * C * N;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // index into W: (k, c, n)
-  if (i >= total) return;
-  const int n = (int)(i % N), c = (int)((i / N) % C), k = (int)(i / ((int64_t)N * C));
-  int64_t o;
-  if (kind == 0) o = ((int64_t)c * K + k) * N + n;
-  else if (kind == 1) o = ((int64_t)k * N + n) * C + c;
-  else o = ((int64_t)n * K + k) * C + c;
-  out[o] = W[i];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {      // index into W: (k, c, n); grid-stride (grid_1d caps the grid)
+    const int n = (int)(i % N), c = (int)((i / N) % C), k = (int)(i / ((int64_t)N * C));
+    int64_t o;
+    if (kind == 0) o = ((int64_t)c * K + k) * N + n;
+    else if (kind == 1) o = ((int64_t)k * N + n) * C + c;
+    else o = ((int64_t)n * K + k) * C + c;
+    out[o] = W[i];
+  }
 }
 
 // ---- backward of the streaming time-window projection (tgcn_cheb_project_windows_f32):
@@ -273,9 +273,9 @@ __global__ __launch_bounds__(kBlock) void windows_wgrad_partial_kernel(const flo
 }
 
 __global__ __launch_bounds__(kBlock) void windows_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int64_t count, int32_t nchunks) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= count) return;
-  float acc = 0.f;
-  for (int z = 0; z < nchunks; ++z) acc += partial[(int64_t)z * count + i];
-  dW[i] = acc;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock) {
+    float acc = 0.f;
+    for (int z = 0; z < nchunks; ++z) acc += partial[(int64_t)z * count + i];
+    dW[i] = acc;
+  }
 }

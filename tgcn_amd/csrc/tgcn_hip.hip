@@ -77,17 +77,15 @@ int tgcn_set_tuning(const char* key, int32_t value) {
 
 int tgcn_profile_start(int32_t capacity) {
   if (capacity <= 0) TGCN_FAIL(TGCN_ERR_INVALID, "profile: capacity %d", capacity);
-  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();
   g_prof.reserve(capacity);
-  g_prof_cap.store(capacity);
+  g_prof_cap = capacity;
   return TGCN_OK;
 }
 
 int tgcn_profile_stop(int32_t* kinds, float* ms, int32_t capacity, int32_t* count) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_cap.store(0);
+  g_prof_cap = 0;
   int n = 0;
   for (auto& r : g_prof) {
     float t = 0.f;
@@ -248,7 +246,8 @@ static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterm
   }
   const bool use_x3 = pv == 3 || (pv == 0 && M >= 8192 && (int64_t)Kc * nterms >= 64);
   // rows of 32 / 64 floats, <= 64 output columns, whole weight resident as bf16 planes: the barrier-free streaming form
-  if (stream_ok && !windows && vec4 && vec_epilogue && (Kc == 32 || Kc == 64) && N <= 64 && x3_stream_lds(Kc, N, nterms) <= kX3StreamMaxLds && M < (int64_t)INT32_MAX &&
+  if (stream_ok && !windows && vec4 && vec_epilogue && (Kc == 32 || Kc == 64) && N <= 64 && x3_stream_lds(Kc, N, nterms) <= kX3StreamMaxLds &&
+      x3_stream_lds(Kc, N, nterms) <= (size_t)lds_optin_limit() && M < (int64_t)INT32_MAX &&
       /* n_vertices is checked by the caller of this function where it matters: project_impl passes it through stream_ok */
       (pv == 6 || (pv == 0 && use_x3 && M * (int64_t)nbatch >= kX3StreamMinRows))) {
     c.kernel = kProjX3Stream;
@@ -1129,6 +1128,21 @@ int tgcn_cheb_forward_pf_f32(void* stream, const tgcn_csr* A, const tgcn_csr_sch
     }
   }
   return TGCN_OK;
+}
+
+// The first step of the project-first form on its own: the vertex-sharded layer (tgcn_amd/dist.py) issues its hops itself -- each one behind
+// an exchange of the previous result's cut rows -- so it needs Z without the recursion that tgcn_cheb_forward_pf_f32 runs behind it.
+int tgcn_cheb_project_first_f32(void* stream, int64_t q, int64_t rows, int32_t C, int32_t K, int32_t N, const float* x, const float* Wcat,
+                                const float* bias, int32_t bias_kind, const int32_t* rowmap, float* Z) {
+  if (!x || !Wcat || !Z) TGCN_FAIL(TGCN_ERR_INVALID, "project_first: null operand");
+  if (q < 1 || rows < 1 || C < 1 || K < 1 || N < 1 || (int64_t)K * N > (int64_t)INT32_MAX) TGCN_FAIL(TGCN_ERR_INVALID, "project_first: bad shape");
+  if (int drc = check_pointer_device(x, (hipStream_t)stream, "project_first")) return drc;
+  const int64_t KN = (int64_t)K * N;
+  const float* a1[1] = {x};
+  const int64_t lda1[1] = {C};
+  if (!rowmap) return project_impl(stream, q * rows, C, (int32_t)KN, 1, a1, lda1, Wcat, bias, bias_kind, rows, 1, 0, Z, KN, 0, 0, N);
+  const int64_t a_bs[1] = {rows * (int64_t)C};
+  return project_impl(stream, rows, C, (int32_t)KN, 1, a1, lda1, Wcat, bias, bias_kind, rows, 1, 0, Z, KN, 0, 0, N, rowmap, 0u, (int32_t)q, a_bs, rows * KN);
 }
 
 static int windows_chunks(int64_t M) { const int64_t c = (M + 16383) / 16384; return (int)(c < 1 ? 1 : (c > 256 ? 256 : c)); }

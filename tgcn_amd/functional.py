@@ -183,6 +183,24 @@ def cheb_project(terms, W, bias, bias_kind, n_vertices, interleave=1, out=None):
 
 
 @_on_device
+def project_first(x3, Wcat, bias, bias_kind, K, N, rowmap=None):
+    """Z = x . [W_0 | ... | W_{K-1}] with the bias on the first N columns (Z_0): the first step of the project-first form as its own call
+    (tgcn_cheb_project_first_f32) for callers that run the recursion themselves -- the vertex-sharded layer exchanges cut rows between its
+    hops.  x3: (q, rows, C); Wcat: (C, K*N) (weight_layout kind 0); bias read at the OUTPUT row; rowmap (int32[rows], nullable): output row of
+    input row m.  -> (q, rows, K*N)"""
+    _lib.require_device(x3, Wcat, bias, rowmap)
+    q, rows, Crow = x3.shape
+    assert x3.is_contiguous() and Wcat.is_contiguous() and tuple(Wcat.shape) == (Crow, K * N) and (rowmap is None or (rowmap.dtype == torch.int32 and rowmap.numel() == rows))
+    if x3.data_ptr() % 16:
+        x3 = x3.clone()
+    Z = torch.empty((q, rows, K * N), dtype=torch.float32, device=x3.device)
+    b = bias.contiguous() if bias is not None else None
+    _lib.check(_lib.lib().tgcn_cheb_project_first_f32(_lib.stream_ptr(), q, rows, Crow, K, N, _lib.ptr(x3), _lib.ptr(Wcat), _lib.ptr(b),
+                                                      bias_kind if b is not None else BIAS_NONE, _lib.ptr(rowmap), _lib.ptr(Z)))
+    return Z
+
+
+@_on_device
 def csr_sddmm(op, rows3, cols3, alpha=1.0, out=None, accumulate=False):
     """dval[e] (+)= alpha * sum_b sum_c rows3[b, row(e), c] * cols3[b, col(e), c] over the stored entries of `op`, in CSR order -> (nnz,).
     The gradient of S = L X w.r.t. the values of L is csr_sddmm(op, dS, X) (tgcn_csr_sddmm_f32)."""
@@ -198,6 +216,23 @@ def csr_sddmm(op, rows3, cols3, alpha=1.0, out=None, accumulate=False):
     return out
 
 
+def _values_guard(op, epoch, values_csr):
+    """Learnable values are packed IN PLACE into one operand per pattern (GraphOperand.update_values), and a backward reads the operand's
+    CURRENT values (hops on op.transpose(), the recomputed basis).  When the same pattern has been packed with OTHER values between a forward
+    and its backward -- two spmm calls with one index and two weight tensors, one ChebConv called twice with computed edge_weights -- the
+    operand no longer holds what this backward differentiates: re-pack the values the forward ran with (saved in ctx), and drop the stamp of
+    the last packing so that the next forward packs its own weight again.  torch's in-place version check cannot see this (the packed
+    entries are not a tensor of the graph); the old per-weight cache key was correct by construction, this keeps the per-pattern operand
+    correct too."""
+    if values_csr is None or op.values_epoch == epoch:
+        return
+    with op._lock:
+        if op.values_epoch != epoch:
+            op.update_values(values_csr)
+            op._packed_stamp = None
+            op._packed_alias = None
+
+
 class SpmmFn(torch.autograd.Function):
     """out = L matrix3 (one hop) as a differentiable op: d matrix = L^T g (the hop on the cached transposed operand), d values = the sampled
     product <g[row(e)], matrix[col(e)]> in CSR order (csr_sddmm) -- the reference's spmm* are differentiable in both (gcn.py:296-308)."""
@@ -206,13 +241,15 @@ class SpmmFn(torch.autograd.Function):
     @_on_device
     def forward(ctx, matrix3, values_csr, op):
         ctx.op = op
-        ctx.save_for_backward(matrix3)
+        ctx.values_epoch = op.values_epoch
+        ctx.save_for_backward(matrix3, None if values_csr is None else values_csr.detach())
         return csr_hop(op, matrix3)
 
     @staticmethod
     @_on_device
     def backward(ctx, g):
-        (matrix3,) = ctx.saved_tensors
+        matrix3, vals = ctx.saved_tensors
+        _values_guard(ctx.op, ctx.values_epoch, vals)
         g = g.contiguous()
         gm = csr_hop(ctx.op.transpose(), g) if ctx.needs_input_grad[0] else None
         gv = csr_sddmm(ctx.op, g, matrix3) if ctx.needs_input_grad[1] else None
@@ -418,13 +455,16 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None, mode=MO
     assert x3.is_contiguous() and Wt.is_contiguous() and Wt.shape[0] == K * Crow and n == plan.n and K >= 2
     if x3.data_ptr() % 16:
         x3 = x3.clone()
+    auto_chunk = False
     if q_chunk is None:
         q_chunk = COMPACT_Q_CHUNK
     if q_chunk is None:
         # time steps per pass: the hops still run one time step per launch; a pass's projection reads a per-vertex bias ONCE for all its
-        # time steps (the streaming projection keeps the bias row of a tile in registers across the samples of the pass), so take up to 16
-        # while the K-1 compact hop tensors of a pass stay within half of the free memory, in passes of equal size.  cfg5 (round 5, same
-        # box): 282.3 / 279.8 / 278.6 ms per forward at 4 / 8 / 16 time steps per pass (77 GB of workspace at 16: HBM3E is 288 GB)
+        # time steps (the streaming projection keeps the bias row of a tile in registers across the samples of the pass).  cfg5 (round 5, same
+        # box): 282.3 / 279.8 / 278.6 ms per forward at 4 / 8 / 16 time steps per pass -- 1.3 % for 77 GB of workspace at 16, so the K-1 compact
+        # hop tensors of a pass are held to COMPACT_WS_FRACTION (a quarter) of the memory that is free when the shape is first seen (cfg5: 8 per
+        # pass, 39 GB), in passes of equal size; an allocation that fails later (the process has allocated more since, or shares the GPU) halves
+        # the choice instead of failing the forward
         q_chunk = 1
         if bias_kind == BIAS_VERTEX_CHANNEL and q > 1:
             key = (K, Crow, q)
@@ -432,17 +472,26 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None, mode=MO
             if q_chunk is None:            # asked once per shape: no host query on later forwards (nor under hipGraph capture)
                 free = torch.cuda.mem_get_info(x3.device)[0]
                 per_q = (K - 1) * (plan.n_c + 1) * Crow * 4
-                most = int(max(1, min(q, 16, (free // 2) // max(per_q, 1))))
+                most = int(max(1, min(q, 16, int(free * COMPACT_WS_FRACTION) // max(per_q, 1))))
                 passes = -(-q // most)
                 q_chunk = plan.q_chunk_cache[key] = -(-q // passes)
+            auto_chunk = True
     sched = plan.schedule_for(Crow, Crow % 4 == 0)
     kept = None
     if keep:
         nt = K if mode == MODE_CHEBYSHEV else K - 1
         kept = torch.empty((nt, q, plan.n_c + 1, Crow), dtype=torch.float32, device=x3.device)
-    ws_bytes = L.tgcn_cheb_compact_layer_workspace_bytes(C.byref(sched.struct), mode, K, q, plan.n_c, Crow, q_chunk, 1 if keep else 0)
-    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
     out = torch.empty((q, n, N), dtype=torch.float32, device=x3.device)
+    while True:
+        ws_bytes = L.tgcn_cheb_compact_layer_workspace_bytes(C.byref(sched.struct), mode, K, q, plan.n_c, Crow, q_chunk, 1 if keep else 0)
+        try:
+            ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=x3.device)
+            break
+        except torch.OutOfMemoryError:
+            if not auto_chunk or q_chunk <= 1:
+                raise
+            torch.cuda.empty_cache()
+            q_chunk = plan.q_chunk_cache[(K, Crow, q)] = max(1, q_chunk // 2)        # the cached choice no longer fits: fewer time steps per pass from now on
     _lib.check(L.tgcn_cheb_compact_layer_f32(_lib.stream_ptr(), C.byref(plan.first.struct), C.byref(plan.rest.struct), C.byref(sched.struct), mode, K, q, n,
                                              Crow, N, _lib.ptr(x3), _lib.ptr(Wt), _lib.ptr(W_left), _lib.ptr(bias), bias_kind, _lib.ptr(out),
                                              _lib.ptr(plan.rows), _lib.ptr(plan.empty), plan.n_empty, _lib.ptr(plan.cid), q_chunk, _lib.ptr(kept),
@@ -456,6 +505,7 @@ def cheb_forward_compact(plan, x3, Wt, bias, bias_kind, K, q_chunk=None, mode=MO
 COMPACT_LAYOUT1 = False           # compact hop tensors for the vertex-major layout too: built and tested, measured on cfg5n (TGCNCheb(L,1,64,5), q = 16 on the
                                   # 10 M-vertex R-MAT): hop 2.08 -> 2.08 ms (64-byte rows: the launch is bound by its 160 M line requests, not by the rows it
                                   # writes), row-mapped projection 10.3 -> 12.2 ms (41 GB of output through a row map instead of one stream) => off
+COMPACT_WS_FRACTION = 0.25       # share of the free device memory the compact hop tensors of one pass may take (cheb_forward_compact)
 COMPACT_SLAB_BYTES = 64 << 20    # a hop launch covers one sample when a sample's (n_c, C) slab is larger (the gather working set stays one slab)
 
 
@@ -879,7 +929,8 @@ class ChebLayerFn(torch.autograd.Function):
             ctx.basis = (rows, nq)
         else:
             out = layer_forward(op, x3, W, fold, b, bias_kind, mode)
-        ctx.save_for_backward(x3, W)
+        ctx.save_for_backward(x3, W, None if values is None else values.detach())
+        ctx.values_epoch = op.values_epoch
         ctx.op, ctx.mode, ctx.bias_kind, ctx.fold = op, mode, bias_kind, fold
         ctx.bias_shape = None if bias is None else bias.shape
         return out
@@ -887,7 +938,8 @@ class ChebLayerFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def backward(ctx, g):
-        x3, W = ctx.saved_tensors
+        x3, W, vals = ctx.saved_tensors
+        _values_guard(ctx.op, ctx.values_epoch, vals)
         gx, gW, gb = layer_backward(ctx.op, ctx.mode, ctx.fold, x3, W, g, ctx.bias_kind, ctx.bias_shape, ctx.needs_input_grad,
                                     basis=ctx.basis)
         values_basis = ctx.basis if (isinstance(ctx.basis, tuple) and len(ctx.basis) == 2 and ctx.mode == MODE_CHEBYSHEV) else None

@@ -290,6 +290,7 @@ class GraphOperand:
         self._sched = {}
         self._lock = threading.RLock()
         self._transpose = None
+        self.values_epoch = 0     # bumped by update_values: which packing of the values a recorded backward belongs to
         self._compact = False     # CompactPlan, None when the operand does not qualify, False until asked
         self.perm = None          # reordered(): internal row i holds the caller's vertex perm[i]
         self.inv_perm = None
@@ -328,6 +329,7 @@ class GraphOperand:
         optimizer step while edge_index does not, and everything expensive -- the COO -> CSR sort, the schedules, the compact plans' row maps --
         depends on the pattern only.  The packed entries, the dense copy, the compact plans' second entry array and the cached transpose (through
         a once-computed entry map) are refreshed; device pointers do not move, so the ctypes structs stay valid."""
+        self.values_epoch += 1          # a backward that was recorded against the previous values notices (functional._values_guard)
         if self.nnz == 0:
             return
         vals = vals.detach().to(device=self.device, dtype=torch.float32).reshape(-1)

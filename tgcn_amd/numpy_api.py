@@ -6,18 +6,62 @@ import torch
 from . import functional as F
 from .graph import GraphOperand
 
-_cache = {}
+import collections
+import threading
+
+
+class _LruCache:
+    """device operands of the scipy / ndarray matrices this module has seen: least recently used beyond `max_entries`, one lock (the
+    reference's numpy scripts are single-threaded, nn.DataParallel replicas of a module holding a scipy L are not)"""
+
+    def __init__(self, max_entries=8):
+        self._d = collections.OrderedDict()
+        self._lock = threading.Lock()
+        self.max_entries = max_entries
+
+    def get(self, key, build):
+        with self._lock:
+            hit = self._d.get(key)
+            if hit is None:
+                hit = self._d[key] = build()
+                while len(self._d) > self.max_entries:
+                    self._d.popitem(last=False)
+            else:
+                self._d.move_to_end(key)
+            return hit
+
+    def __len__(self):
+        return len(self._d)
+
+
+_cache = _LruCache()
+
+
+def _digest(*arrays):
+    """128-bit hash of the arrays' bytes (xxh3 when the package is there, blake2b otherwise): O(nnz) on the host per call, a fraction of a
+    second per GB -- negligible next to the device build it guards, and the price of a scipy / ndarray operand having no version counter"""
+    try:
+        import xxhash
+        h = xxhash.xxh3_128()
+    except ImportError:
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(memoryview(a).cast("B"))
+    return h.hexdigest()
 
 
 def _fingerprint(L):
-    """Cheap content tag so that in-place edits of a scipy / ndarray operand are (very likely) noticed: the callers
-    rebuild or rescale L between calls (examples/gcn_mnist.py:131)."""
+    """Content hash of a scipy / ndarray operand -- values AND pattern: the callers rebuild or rescale L between calls
+    (examples/gcn_mnist.py:131), and gcn/graph.py:232-238 rescale_L edits L.data in place for lmax != 2.  The round-5 tag (address + first and
+    last 32 values) served the old device CSR after an edit in the middle of L.data."""
     data = getattr(L, "data", None)
-    if isinstance(data, np.ndarray) and data.size:
-        return (data.ctypes.data, data[:32].tobytes(), data[-32:].tobytes())
-    if isinstance(L, np.ndarray) and L.size:
-        flat = L.reshape(-1)
-        return (L.ctypes.data, flat[:32].tobytes(), flat[-32:].tobytes())
+    if isinstance(data, np.ndarray) and not isinstance(L, np.ndarray):         # scipy.sparse: values + whichever index arrays the format has
+        idx = [getattr(L, name) for name in ("indices", "indptr", "row", "col", "offsets") if isinstance(getattr(L, name, None), np.ndarray)]
+        return (getattr(L, "format", None), tuple(L.shape), _digest(data, *idx))
+    if isinstance(L, np.ndarray):
+        return ("ndarray", tuple(L.shape), str(L.dtype), _digest(L))
     return None
 
 
@@ -28,15 +72,13 @@ def _chebyshev_f64(L, X, K, device):
     # the caller's matrix is never touched (tocsr() of a CSR returns the object itself), and entries keep their stored order,
     # which is the order the reference's L.dot sums them in (gcn/graph.py:256-265)
     key = ("f64", id(L), getattr(L, "nnz", None), _fingerprint(L), str(device))
-    hit = _cache.get(key)
-    if hit is None:                      # the device CSR is kept like the fp32 operand (gcn_mnist.py calls this per batch with one L)
+
+    def build():                         # the device CSR is kept like the fp32 operand (gcn_mnist.py calls this per batch with one L)
         Lc = L.tocsr() if hasattr(L, "tocsr") else __import__("scipy.sparse").sparse.csr_matrix(np.asarray(L))
-        if len(_cache) > 8:
-            _cache.clear()
-        hit = _cache[key] = ((Lc.shape[0], torch.as_tensor(Lc.indptr.astype(np.int32), device=device),
-                              torch.as_tensor(Lc.indices.astype(np.int32), device=device),
-                              torch.as_tensor(Lc.data.astype(np.float64), device=device)), L)      # L kept alive: a freed object's id can come back
-    n, rp, ci, va = hit[0]
+        return ((Lc.shape[0], torch.as_tensor(Lc.indptr.astype(np.int32), device=device),
+                 torch.as_tensor(Lc.indices.astype(np.int32), device=device),
+                 torch.as_tensor(Lc.data.astype(np.float64), device=device)), L)      # L kept alive: a freed object's id can come back
+    n, rp, ci, va = _cache.get(key, build)[0]
     lib = _lib.lib()
 
     def hop(x, z, alpha, beta, y, p):
@@ -71,12 +113,7 @@ def chebyshev(L, X, K, device="cuda"):
     if getattr(L, "dtype", None) == np.float64:
         return _chebyshev_f64(L, X, K, device)
     key = (id(L), getattr(L, "nnz", None), _fingerprint(L), str(device))
-    hit = _cache.get(key)
-    if hit is None:
-        if len(_cache) > 8:
-            _cache.clear()
-        hit = _cache[key] = (GraphOperand.from_any(L, device), L)     # L kept alive: a freed object's id can come back
-    op = hit[0]
+    op = _cache.get(key, lambda: (GraphOperand.from_any(L, device), L))[0]     # L kept alive: a freed object's id can come back
     out_dtype = L.dtype if hasattr(L, "dtype") else X.dtype
     if X.ndim == 2:
         x3 = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32), device=device).unsqueeze(0)
