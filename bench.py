@@ -270,16 +270,20 @@ def other_workload_entry(name, device, steps=20, warmup=5):
         for _ in range(warmup):
             out = layer(x)
         torch.cuda.synchronize()
-        _lib.profile_start(8192)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out = layer(x)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        prof = _lib.profile_stop(8192)
+        # three rounds of `steps` forwards, the best one reported (all three kept in `rounds_ms`): these configurations take 40 ... 350 us per
+        # forward, and the first round after the 150 GB of the headline were handed back to the driver has been seen 20 x slower than the next
+        rounds = []
+        for _ in range(3):
+            _lib.profile_start(8192)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = layer(x)
+            torch.cuda.synchronize()
+            rounds.append((time.perf_counter() - t0, _lib.profile_stop(8192)))
+        dt, prof = min(rounds, key=lambda r: r[0])
     units = op.nnz * (K - 1) * q * H
     entry = dict(workload=spec["desc"], config=name, ms_per_step=round(dt / steps * 1e3, 4), value=round(units * steps / dt / 1e9, 3), unit="G edge\u00b7timesteps/s",
-                 steps=steps, warmup=warmup, dtype="f32")
+                 steps=steps, warmup=warmup, dtype="f32", rounds_ms=[round(r[0] / steps * 1e3, 4) for r in rounds])
     by_kind = {}
     for kind, ms in prof:
         by_kind.setdefault(kind, []).append(ms)

@@ -415,9 +415,12 @@ int tgcn_cheb_forward_small_pool_f32(void* stream, const tgcn_csr* A, int32_t mo
 int tgcn_relu_pool_f32(void* stream, const float* x, float* out, uint8_t* idx, int64_t q, int64_t n, int32_t f, int32_t p);
 
 /* The layer of tgcn_cheb_forward_f32 followed by relu + max over `pool` consecutive vertices for graphs that do NOT fit in LDS:
- * out (q, n/pool, N), pool_idx (nullable) as above.  On the (q, n, C) layout with up to 32 terms and N <= 64 output columns
- * the epilogue runs inside the projection kernel (bias, relu and the max over 2 / 4 / 8 / 16 rows of the finished tile), so the
- * (q, n, N) layer output is never written; other shapes run the layer into workspace scratch followed by tgcn_relu_pool_f32
+ * out (q, n/pool, N), pool_idx (nullable) as above.  On the (q, n, C) layout with up to 32 terms the epilogue runs inside the projection
+ * kernel -- N <= 64 output columns: bias, relu and the max over 2 / 4 / 8 / 16 rows of the finished tile in the wave's LDS scratch;
+ * N >= 96 on the bf16x3 path (ABI v7): groups of 2 / 4 rows folded in registers, a lane's four accumulators of a column being four
+ * consecutive rows -- so the (q, n, N) layer output is never written; other shapes (the vertex-major layout 1 of rows shorter than 32
+ * floats, groups of 8 / 16 with wide outputs) run the layer into workspace scratch followed by tgcn_relu_pool_f32: measured 0 - 1.3 % of the
+ * fused call on the layout-1 shapes of the reference's HCP model at mesh size (profiles/r06_pool_epilogue_cost.jsonl), final as it is
  * (the workspace query accounts for it; it returns 0 only for invalid arguments -- a K = 1 layer on a schedule without partial rows has
  * a base figure of 0 and still gets its output scratch).  pool = 1: relu only.
  * Alignment: the fused epilogue needs `out` and `bias` 16-byte aligned and `pool_idx` 4-byte aligned.  The query decides fused vs two-pass

@@ -194,7 +194,7 @@ def test_reordered_operand_in_forward_series_and_to(kind, gpu_device):
 
 
 @pytest.mark.parametrize("case", ["mesh59k_gcn32x64_pool4", "mesh90k_tgcn64x64_pool2", "grid_exact_pool4", "mesh_layout1_fallback",
-                                  "mesh_k1_wide_fallback"])
+                                  "mesh_k1_wide", "mesh59k_gcn64x128_pool4_wide", "mesh_tgcn32x160_pool2_wide", "mesh_wide_pool8_fallback"])
 def test_relu_pool_in_the_projection_epilogue(case, gpu_device):
     """SURVEY 8f-2 for graphs that do not fit in LDS: bias + relu + max over 2 / 4 consecutive vertices inside the projection's
     epilogue (tgcn_cheb_forward_pool_f32) -- against the ORACLE's pool(relu(forward)) on the 59,536-vertex mesh and at 90 k
@@ -216,9 +216,21 @@ def test_relu_pool_in_the_projection_epilogue(case, gpu_device):
         n, row, col, val = synth.sheet_mesh(40)
         mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 32, 16, 3)), 2, 32, 4, True
         ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
-    elif case == "mesh_k1_wide_fallback":         # K = 1 on a schedule without partial rows has a base workspace of 0 bytes, and
-        n, row, col, val = synth.sheet_mesh(100)  # 96 output columns cannot take the fused epilogue: the query must still size the output scratch
-        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 64, 96, 1)), 1, 64, 4, False
+    elif case == "mesh_k1_wide":                  # K = 1, 96 output columns: since round 6 the wide bf16x3 kernel folds groups of 2 / 4 rows in registers
+        n, row, col, val = synth.sheet_mesh(100)
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 64, 96, 1)), 1, 64, 4, True
+        ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
+    elif case == "mesh59k_gcn64x128_pool4_wide":  # >= 96 output columns (project_x3v2_kernel), per-channel bias, ragged last tile
+        n, row, col, val = synth.sheet_mesh(244)
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 64, 128, 3)), 2, 64, 4, True
+        ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
+    elif case == "mesh_tgcn32x160_pool2_wide":    # ten column tiles, per-vertex bias, groups of two, two samples in one launch
+        n, row, col, val = synth.sheet_mesh(150)
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.TGCNCheb(o, 32, 160, 3)), 2, 32, 2, True
+        ref = lambda L, x, W, b: O.tgcn_cheb_forward(L, x, W, b)
+    elif case == "mesh_wide_pool8_fallback":      # K = 1 on a schedule without partial rows has a base workspace of 0 bytes, and groups of 8
+        n, row, col, val = synth.sheet_mesh(100)  # rows do not fit a lane's four accumulators: the query must still size the output scratch
+        mk, q, C, pool, fused = (lambda o: tgcn_amd.GCNCheb(o, 64, 96, 1)), 1, 64, 8, False
         ref = lambda L, x, W, b: O.gcn_cheb_forward(L, x, W, b)
     else:
         n, row, col, val = synth.sheet_mesh(60)
@@ -260,6 +272,6 @@ def test_relu_pool_in_the_projection_epilogue(case, gpu_device):
     layer.zero_grad()
     x2 = _dev(x).requires_grad_(True)
     yy = torch.relu(layer(x2))
-    (tgcn_amd.gcn_pool_4(yy) if pool == 4 else tgcn_amd.gcn_pool(yy)).backward(gz)
+    (tgcn_amd.gcn_pool_4(yy) if pool == 4 else (tgcn_amd.gcn_pool(yy) if pool == 2 else F.PoolMaxFn.apply(yy, pool))).backward(gz)
     for a, b in zip(g1, [x2.grad, layer.weight.grad, layer.bias.grad]):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5

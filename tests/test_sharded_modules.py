@@ -256,3 +256,41 @@ def test_no_object_collective_in_the_shard_code():
     """index lists travel as tensors (count exchange + all_to_all_single), never as pickled Python objects"""
     src = open(os.path.join(os.path.dirname(__file__), "..", "tgcn_amd", "dist.py")).read()
     assert "all_gather_object" not in src and "broadcast_object" not in src and "gather_object" not in src
+
+
+def test_row_bounds_can_respect_pool_groups():
+    """gcn_pool_4 between two sharded layers (pytorch_hcp_tgcn.py:134-141) pools 4 consecutive vertices: row_multiple=4 keeps every group on one rank"""
+    from tgcn_amd.dist import balanced_row_bounds
+    g = torch.Generator().manual_seed(0)
+    row = torch.randint(0, 1003, (9000,), generator=g)
+    for world in (2, 3, 8):
+        b = balanced_row_bounds(row, 1003, world, multiple=4).tolist()
+        assert b[0] == 0 and b[-1] == 1003 and all(x % 4 == 0 for x in b[1:-1]) and all(b[i] <= b[i + 1] for i in range(world))
+        plain = balanced_row_bounds(row, 1003, world).tolist()
+        assert all(abs(x - y) <= 2 for x, y in zip(b, plain))
+
+
+def _sync_init_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import scipy.sparse as sp
+        from tgcn_amd import dist as tdist
+        n = 120
+        row, col, val = _graph(n, 19, True)
+        Lsp = sp.coo_matrix((val, (row, col)), shape=(n, n)).tocsr()
+        torch.manual_seed(1000 + rank)                        # every rank draws OTHER parameters ...
+        mod = tdist.ShardedGCNCheb(Lsp, 2, 3, 3, ops=CpuOps(), row_multiple=4)
+        before = mod.weight.detach().clone()
+        sh = mod.shard("cpu")                                 # ... and the first rank's are broadcast when the shard is built
+        ws = [torch.empty_like(mod.weight) for _ in range(world)]
+        dist.all_gather(ws, mod.weight.detach().contiguous())
+        ret[rank] = (all(torch.equal(w, ws[0]) for w in ws), bool(torch.equal(before, mod.weight.detach())), sh.lo % 4, sh.hi % 4 if sh.hi != n else 0)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameters_follow_the_groups_first_rank():
+    res = _spawn(_sync_init_worker, 3)
+    assert all(r[0] for r in res) and res[0][1] and not res[1][1] and not res[2][1]
+    assert all(r[2] == 0 and r[3] == 0 for r in res)

@@ -749,11 +749,18 @@ __device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* ld
   const int total = p.nterms * ktiles;
   // per-lane, tile-invariant parts of every address (the loop below adds only wave-uniform tile offsets: the vector ALU
   // is the co-bottleneck of this kernel -- an MFMA holds vector issue for 8 of its 16 cycles)
-  int64_t rowc[RT];
+  int64_t rowc[RT], rowm[RT];
+  const uint32_t mapped_bits = p.rowmap ? (p.mapped & ~kProjMapTermsOnly) : 0u;
+  const bool any_mapped = mapped_bits != 0u;
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
     const int64_t m = m0 + wave * (16 * RT) + r * 16 + r16;
     rowc[r] = m < p.M ? m : p.M - 1;                 // rows past the end re-read the last row; their results are never stored
+    // the row a MAPPED term reads, fetched once per tile row (round 6: proj_arow inside load_a re-read the map and re-tested the pointer for
+    // every load of every k tile -- with a row map that maps no term at all, as the vertex shards' Z projection passes, cfg4's
+    // 90 k x 1200 x 160 contraction went from 0.22 to 0.30 ms)
+    // (kept as the DIFFERENCE to the tile row: `tm ? rowm[r] : rowc[r]` becomes a select between two arrays, which puts both into scratch)
+    rowm[r] = any_mapped ? (int64_t)p.rowmap[rowc[r]] - rowc[r] : 0;
   }
   int wsrc[WPAIRS], wdst[WPAIRS], wkk[WPAIRS];
   bool wcol[WPAIRS];
@@ -771,12 +778,13 @@ __device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* ld
     const int term = ti / ktiles, k0 = (ti % ktiles) * KT;           // wave-uniform
     const float* __restrict__ A = p.a[term] + k0 + kg * 8;
     const int64_t lda = p.lda[term];
+    const int64_t tm = -(int64_t)((mapped_bits >> term) & 1u);       // wave-uniform mask: all ones for a mapped term
     if (k0 + KT <= p.Kc) {
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float4 v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rowc[r]) * lda + h * 4);
+          const float4 v = *reinterpret_cast<const float4*>(A + (rowc[r] + (rowm[r] & tm)) * lda + h * 4);
           dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
         }
     } else {                                                         // last k tile of a term: k past Kc reads as zero
@@ -786,7 +794,7 @@ __device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* ld
         for (int h = 0; h < 2; ++h) {
           const bool ok = k0 + kg * 8 + h * 4 < p.Kc;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok) v = *reinterpret_cast<const float4*>(A + proj_arow(p, term, rowc[r]) * lda + h * 4);
+          if (ok) v = *reinterpret_cast<const float4*>(A + (rowc[r] + (rowm[r] & tm)) * lda + h * 4);
           dst[r][h * 4 + 0] = v.x; dst[r][h * 4 + 1] = v.y; dst[r][h * 4 + 2] = v.z; dst[r][h * 4 + 3] = v.w;
         }
     }
@@ -877,7 +885,9 @@ __device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* ld
   // load right after its split measured 0.219 / 0.225 ms: not it (docs/EXPERIMENTS.md A.5).  Only full 32-k tiles run here; the last two (and a
   // partial one) drain through the plain loop.  Bitwise the plain loop's result (same products, same order).
   const int nfull = (p.Kc % KT == 0) ? total : (p.nterms == 1 ? ktiles - 1 : 0);
-  if (NT >= 6 && nfull >= 4 && !p.rowmap) {
+  // (a row map that maps no TERM -- output rows only, as the vertex shards' Z projection passes -- takes this loop too since round 6: the
+  //  `!p.rowmap` it was guarded by sent that call through the plain loop, 0.26 -> 0.31 ms on cfg4's contraction)
+  if (NT >= 6 && nfull >= 4 && !any_mapped) {
     float rn[RT][8];
     bf16x8 a_cur[RT][3], a_next[RT][3];
     auto load_a_full = [&](int t, float (&dst)[RT][8]) {            // full tiles only: no bounds on k
@@ -975,36 +985,95 @@ __device__ __forceinline__ void x3v2_body(const ProjParams& p, unsigned char* ld
     __syncthreads();
   }
   // ---- epilogue
-  if constexpr (NT <= 4) {
-    if (p.vec_epilogue) {
-      constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
-      float* my = reinterpret_cast<float*>(lds_raw) + wave * (16 * ES);     // the loop ended with a barrier: W buffers are free
+  // through the wave's LDS scratch for EVERY width (round 6; the kernel's LDS was already sized for it): 16-byte bias loads and 16-byte stores of
+  // whole 640-byte rows.  Until round 5 the widths this kernel is actually chosen for (>= 96 columns) took the scalar form below -- 80 dependent
+  // bias-load / wait / add / 4-byte-store sequences per lane at one workgroup per CU.
+  if (p.vec_epilogue && p.pool <= 1) {
+    constexpr int SEGS = NW / 4, ITER = (16 * SEGS) / 64;
+    float* my = reinterpret_cast<float*>(lds_raw) + wave * (16 * ES);     // the loop ended with a barrier: W buffers are free
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
+    for (int r = 0; r < RT; ++r) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) my[(kg * 4 + i) * ES + nt * 16 + r16] = acc[r][nt][i];
+        for (int i = 0; i < 4; ++i) my[(kg * 4 + i) * ES + nt * 16 + r16] = acc[r][nt][i];
+      // three passes over the lane's ITER 16-byte pieces: the row-map entries, then the bias pieces (their address depends on the mapped row),
+      // then the LDS reads and the stores.  Left interleaved, every piece is a chain  map load -> wait -> bias load -> wait -> store  (the stores
+      // may alias anything as far as the compiler knows): 20 round trips to memory per lane at one workgroup per CU, measured +0.05 ms on a
+      // 45 k-row tile round (tools/proj_rowmap_cost.py)
+      int64_t orow_[ITER];
+      float4 bv_[ITER];
+      bool ok_[ITER];
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-          const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
-          const int64_t m = m0 + wave * (16 * RT) + r * 16 + row;
-          const int col = n0 + seg;
-          if (m >= p.M || col >= p.N) continue;
-          float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
-          const int64_t orow = proj_orow(p, m);
-          if (p.bias_kind && col < p.bias_cols) {
-            const int64_t vert = orow < p.n_vertices ? orow : orow % p.n_vertices;
-            const float4 bv = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-          }
-          float4* o = reinterpret_cast<float4*>(p.out + orow * p.ldo + col);
-          if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
-          *o = v;
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+        const int64_t m = m0 + wave * (16 * RT) + r * 16 + row;
+        ok_[it] = m < p.M && n0 + seg < p.N;
+        orow_[it] = proj_orow(p, ok_[it] ? m : p.M - 1);
+      }
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int col = n0 + ((lane + 64 * it) % SEGS) * 4;
+        bv_[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok_[it] && p.bias_kind && col < p.bias_cols) {
+          const int64_t vert = orow_[it] < p.n_vertices ? orow_[it] : orow_[it] % p.n_vertices;
+          bv_[it] = *reinterpret_cast<const float4*>(p.bias + (p.bias_kind == 2 ? vert * p.bias_ld : 0) + col);
         }
       }
-      return;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        if (!ok_[it]) continue;
+        const int idx = lane + 64 * it, row = idx / SEGS, seg = (idx % SEGS) * 4;
+        float4 v = *reinterpret_cast<const float4*>(&my[row * ES + seg]);
+        v.x += bv_[it].x; v.y += bv_[it].y; v.z += bv_[it].z; v.w += bv_[it].w;
+        float4* o = reinterpret_cast<float4*>(p.out + orow_[it] * p.ldo + n0 + seg);
+        if (p.accumulate) { const float4 ov = *o; v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w; }
+        *o = v;
+      }
     }
+    return;
+  }
+  if (p.pool > 1) {
+    // fused relu + max over p.pool in {2, 4} consecutive tile rows (round 6: the wide kernel too): the four accumulators a lane holds for one
+    // column ARE four consecutive rows (D[row = 4 (l >> 4) + i][col = l & 15]), so the groups are folded in registers -- bias first (it differs
+    // per vertex), first maximum wins, NaN propagates: relu_pool_kernel's rules -- and the lane stores one float per group (16 lanes = 64
+    // contiguous bytes of a pooled row).  M % pool == 0 and the tile's row base is a multiple of 4: a group lies inside M as a whole or not at all.
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const int64_t mb = m0 + wave * (16 * RT) + r * 16 + kg * 4;
+      if (mb >= p.M) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + r16;
+        if (col >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[r][nt][i];
+          if (p.bias_kind == 1 && col < p.bias_cols) v[i] += p.bias[col];
+          else if (p.bias_kind == 2 && col < p.bias_cols && mb + i < p.M) v[i] += p.bias[((mb + i) % p.n_vertices) * p.bias_ld + col];     // (a lane's four rows may straddle two samples when n % 4 == 2; a group never does)
+        }
+        // (static indices only: a runtime-indexed v[] would live in scratch memory)
+        auto later = [](float c, float best) { return c > best || (c != c && best == best); };
+        auto emit = [&](int64_t m, float best, int bi) {
+          const int64_t orow = m / p.pool;
+          p.out[orow * p.ldo + col] = best > 0.f ? best : (best != best ? best : 0.f);
+          if (p.pool_idx) p.pool_idx[orow * p.ldo + col] = (uint8_t)bi;
+        };
+        float b01 = v[0], b23 = v[2];
+        int i01 = 0, i23 = 0;
+        if (later(v[1], b01)) { b01 = v[1]; i01 = 1; }
+        if (later(v[3], b23)) { b23 = v[3]; i23 = 1; }
+        if (p.pool == 2) {
+          emit(mb, b01, i01);
+          if (mb + 2 < p.M) emit(mb + 2, b23, i23);
+        } else {              // pool == 4: entries 0, 1, 2, 3 in order, the first maximum wins
+          if (later(b23, b01)) { b01 = b23; i01 = 2 + i23; }
+          emit(mb, b01, i01);
+        }
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int r = 0; r < RT; ++r)

@@ -220,6 +220,7 @@ struct ProjChoice {
   int nts;           // 16-column tiles per workgroup of the streaming / bf16x3 kernels
   size_t wbytes;     // LDS image of the weight for the W-resident kernel
   bool pool_epilogue;   // the kernel can end in relu + max over consecutive rows (through its vector epilogue)
+  int pool_max;         // ... over groups whose size divides this: 16 (rows of a wave's tile in LDS scratch), 4 in the wide bf16x3 kernel (a lane's four accumulator rows)
 };
 // stream_ok: the call has nothing the streaming kernel lacks (pool epilogue, fused last hop, accumulate, interleave, windows) -- project_impl knows,
 // the shape-only queries (pool / gather fusability) pass false: those forms live in project_x3_kernel.
@@ -239,6 +240,7 @@ static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterm
     c.nts = best;
   }
   c.pool_epilogue = false;
+  c.pool_max = 16;
   (void)has_rowmap;     // every kernel reads mapped terms / writes mapped rows through proj_arow / proj_orow
   if ((pv == 0 || pv == 5) && (int64_t)Kc * nterms <= kNarrowMaxK && !windows && vec_epilogue && N <= 1024 && (M >= 4096 || pv == 5)) {
     c.kernel = kProjNarrow;           // a few scalars per row: the output streams from the vector ALU
@@ -260,7 +262,8 @@ static ProjChoice project_choose(int64_t M, int32_t Kc, int32_t N, int32_t nterm
   }
   if (use_x3) {
     c.kernel = (vec4 && c.nts >= 6 && g_x3_form.load() == 2) ? kProjX3Wide : kProjX3;      // wide outputs: A fragments from registers
-    c.pool_epilogue = c.kernel == kProjX3 && c.nts <= 4 && vec_epilogue;
+    c.pool_epilogue = (c.kernel == kProjX3 && c.nts <= 4 && vec_epilogue) || c.kernel == kProjX3Wide;
+    if (c.kernel == kProjX3Wide) c.pool_max = 4;
     return c;
   }
   c.kernel = kProjStream;
@@ -277,7 +280,8 @@ static bool project_gather_fusable(int64_t M, int32_t Kc, int32_t N, int32_t nte
 // Whether the projection of this shape (aligned operands, no row map) ends in a kernel with the fused relu + pool epilogue.
 static bool project_pool_fusable(int64_t M, int32_t Kc, int32_t N, int32_t nterms, int32_t pool) {
   if (pool < 2 || 16 % pool != 0 || M % pool != 0 || N % 4 != 0 || nterms > kMaxTerms) return false;
-  return project_choose(M, Kc, N, nterms, Kc % 4 == 0, true, false, false).pool_epilogue;
+  const ProjChoice c = project_choose(M, Kc, N, nterms, Kc % 4 == 0, true, false, false);
+  return c.pool_epilogue && c.pool_max % pool == 0;
 }
 
 int tgcn_cheb_project_f32(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t nterms, const float* const* a,
@@ -345,7 +349,8 @@ static int project_impl(void* stream, int64_t M, int32_t Kc, int32_t N, int32_t 
   if (rowmap && interleave != 1 && choice.kernel != kProjNarrow)
     TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: a row map together with interleave is the vector-ALU kernel's form (nterms*Kc <= %d, N %% 4 == 0, M >= 4096)", kNarrowMaxK);
   if (pool > 1) {     // fused relu + max-pool epilogue: only where the dispatch takes a kernel that has it
-    if (rowmap || interleave != 1 || accumulate || win_n != 0 || nbatch != 1 || pool < 2 || 16 % pool != 0 || M % pool != 0 || !choice.pool_epilogue)
+    if (rowmap || interleave != 1 || accumulate || win_n != 0 || nbatch != 1 || pool < 2 || choice.pool_max % pool != 0 || M % pool != 0 || !choice.pool_epilogue ||
+        n_vertices % pool != 0)
       TGCN_FAIL(TGCN_ERR_UNSUPPORTED, "project: no fused pool epilogue for this shape (M=%lld Kc=%d N=%d terms=%d pool=%d)", (long long)M, Kc, N, nterms, pool);
     p.pool = pool; p.pool_idx = pool_idx;
   }

@@ -64,14 +64,17 @@ def hybrid_groups(world, vertex_shards, rank=None):
     return mine, rank // vertex_shards, ngroups
 
 
-def balanced_row_bounds(row, n, world):
+def balanced_row_bounds(row, n, world, multiple=1):
     """world+1 row boundaries with ~equal stored entries per shard (power-law rows => not equal row counts).  `row`: the row ids of the
-    WHOLE entry list (any order)."""
+    WHOLE entry list (any order).  multiple > 1: inner boundaries rounded to a multiple of it, so that groups of `multiple` consecutive
+    vertices (gcn_pool / gcn_pool_4 between two sharded layers, tgcn/nn/gcn.py:246-255) never straddle two ranks."""
     counts = torch.bincount(row, minlength=n)
     cum = torch.cumsum(counts, 0)
     total = int(cum[-1].item()) if n else 0
     marks = (torch.arange(1, world, device=row.device, dtype=torch.int64) * total) // world
     inner = (torch.searchsorted(cum, marks) + 1).clamp_(max=n)
+    if multiple > 1:
+        inner = ((inner + multiple // 2) // multiple * multiple).clamp_(max=n // multiple * multiple)
     b = torch.cat([torch.zeros(1, dtype=torch.int64, device=row.device), inner,
                    torch.full((1,), n, dtype=torch.int64, device=row.device)])
     return torch.cummax(b, 0)[0]
@@ -178,7 +181,7 @@ class VertexShardedCheb:
                "auto": allgather when the halo is more than half of the remote vertices.
     """
 
-    def __init__(self, n, row, col, val, group=None, device=None, exchange="auto", bounds=None, ops=None):
+    def __init__(self, n, row, col, val, group=None, device=None, exchange="auto", bounds=None, ops=None, row_multiple=1):
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         # point-to-point peers are named by GLOBAL rank; inside a sub-group (hybrid layout) translate the group index
@@ -197,7 +200,7 @@ class VertexShardedCheb:
         val = val.to(device=self.device, dtype=torch.float32)
         self.n = int(n)
         if bounds is None:
-            self.bounds = balanced_row_bounds(row, self.n, self.world)
+            self.bounds = balanced_row_bounds(row, self.n, self.world, row_multiple)
         else:
             self.bounds = torch.as_tensor(bounds, dtype=torch.int64).to(self.device)
             assert self.bounds.numel() == self.world + 1 and int(self.bounds[0]) == 0 and int(self.bounds[-1]) == self.n
@@ -379,6 +382,7 @@ class VertexShardedCheb:
         halo: `src_ext` (1, n_ext, w) with its owned part valid -- messages are packed by the pack kernel into per-peer send buffers and
         received IN PLACE into its own halo region.  all-gather: `mine` (n_max, w) block of this rank -> `src_ext` (1, world * n_max, w)."""
         w = src_ext.shape[2]
+        self._fence()
         if self.exchange != "halo":
             h = dist.all_gather_into_tensor(src_ext.view(self.world * self.n_max, w), mine, group=self.group, async_op=async_op)
             return [h] if h is not None else []
@@ -395,6 +399,15 @@ class VertexShardedCheb:
                 self.ops.pack(src_ext[0], idx, sb)
                 ops.append(dist.P2POp(dist.isend, sb, self.peer[p], group=self.group))
         return dist.batch_isend_irecv(ops) if ops else []
+
+    def _fence(self):
+        """RCCL collectives are ordered on the device's streams (the exchange is enqueued behind the kernels that produce its data, wait() is a
+        stream dependency).  A HOST transport is not: gloo reads and writes device memory from the CPU the moment a send / receive is posted --
+        while the pack kernel that fills the send buffer, or a hop that still reads the buffer a receive lands in, may only be queued
+        (measured on cfg4 with two gloo ranks on one GPU: results off by 2.5 % and different from run to run without this).  So before posting on
+        anything but nccl the device drains.  Rehearsal transports only; the RCCL path never takes it."""
+        if self.device.type == "cuda" and self.comm_device.type != "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _hop(self, op, src, z, alpha, beta, z2, gamma, out):
         if z is None and z2 is not None:
@@ -567,12 +580,14 @@ class VertexShardedCheb:
                 gx = T.forward(g, ops.weight_layout(Wt, 1), None, 0, mode, overlap=overlap, depth=depth)
         if needs[1]:
             gW = gW.contiguous()
+            self._fence()
             dist.all_reduce(gW, op=dist.ReduceOp.SUM, group=grad_group)
             if mode == 0:
                 gW = ops.fold(gW, transpose=True)
         if needs[2] and bias_kind:
             if bias_kind == 1:
                 gb = g.sum(dim=(0, 1))
+                self._fence()
                 dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=grad_group)
             else:
                 gb = g.sum(dim=0)
@@ -627,8 +642,9 @@ class _ShardedMixin:
     device of x), collectively, and with it the parameters are broadcast from the group's first rank (as DataParallel replicates device
     0's, pytorch_hcp_tgcn.py:271).  world size 1: the single-GPU module's own path (compact plans, one-launch kernels, ...)."""
 
-    def _init_sharding(self, group, exchange, ops, sync_bias_grad, grad_group, sync_init):
+    def _init_sharding(self, group, exchange, ops, sync_bias_grad, grad_group, sync_init, bounds=None, row_multiple=1):
         self._group, self._exchange, self._shard_ops = group, exchange, ops
+        self._bounds, self._row_multiple = bounds, row_multiple
         self._grad_group = grad_group
         self._sync_bias_grad, self._sync_init = sync_bias_grad, sync_init
         self._shards = {}
@@ -641,7 +657,7 @@ class _ShardedMixin:
         if sh is None:
             n, row, col, val = _coo_of(self.L, device)
             sh = self._shards[str(device)] = VertexShardedCheb(n, row, col, val, group=self._group, device=device, exchange=self._exchange,
-                                                               ops=self._shard_ops)
+                                                               ops=self._shard_ops, bounds=self._bounds, row_multiple=self._row_multiple)
             if self._sync_init and sh.world > 1:
                 src = sh.peer[0]
                 for p in self.parameters():
@@ -673,9 +689,10 @@ def _sharded_class(base, doc):
     from . import nn as _nn
 
     class Sharded(_ShardedMixin, getattr(_nn, base)):
-        def __init__(self, *args, group=None, exchange="auto", ops=None, sync_bias_grad=True, grad_group=None, sync_init=True, **kw):
+        def __init__(self, *args, group=None, exchange="auto", ops=None, sync_bias_grad=True, grad_group=None, sync_init=True, bounds=None,
+                     row_multiple=1, **kw):
             getattr(_nn, base).__init__(self, *args, **kw)
-            self._init_sharding(group, exchange, ops, sync_bias_grad, grad_group, sync_init)
+            self._init_sharding(group, exchange, ops, sync_bias_grad, grad_group, sync_init, bounds, row_multiple)
 
         def forward(self, x_local):
             if self._single_gpu():

@@ -14,7 +14,7 @@ python3 tools/merge_bench_lines.py $tag > $out/merge.log 2>&1
 echo "== traffic" | tee -a $out/steps.log
 timeout -k 10 1500 bash tools/collect_traffic.sh $tag > $out/traffic.log 2>&1 || echo "traffic rc=$?" | tee -a $out/steps.log
 echo "== projection limiter" | tee -a $out/steps.log
-timeout -k 10 1500 python3 tools/pmc_limiter.py ${tag}_proj --labelings random --script bench.py --extra "--steps 1 --warmup 1 --no-cpu --no-ceiling" \
+timeout -k 10 1500 python3 tools/pmc_limiter.py ${tag}_proj --labelings random --script bench.py --extra "--steps 1 --warmup 1 --no-cpu --no-ceiling --no-others" \
   --kernels hop_fixup_kernel,hop_kernel,project_x3_stream_kernel --only-blocks TCP,TCC,SQ,GRBM --limit 240 > $out/proj_limiter.log 2>&1 || echo "proj limiter rc=$?" | tee -a $out/steps.log
 echo "== cold-nt TCC" | tee -a $out/steps.log
 for v in 6 5; do

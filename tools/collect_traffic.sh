@@ -9,10 +9,10 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --no-ceiling > $out/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu --no-ceiling > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu --no-ceiling > $out/pmc_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_tcc -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu --no-ceiling > $out/pmc_tcc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --no-ceiling --no-others > $out/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu --no-ceiling --no-others > $out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu --no-ceiling --no-others > $out/pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_tcc -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu --no-ceiling --no-others > $out/pmc_tcc.log 2>&1
 cd $root
 python3 tools/traffic_json.py $out/traffic_cfg5_random.json $out/pmc_fetch $out/pmc_write $out/pmc_tcc
 cp $(ls $out/kt/*/*kernel_stats.csv | head -1) $out/${tag}_cfg5_random_kernel_stats.csv
