@@ -143,3 +143,23 @@ def test_training_step_is_hipgraph_capturable(gpu_device):
         g.replay()
         got.append(float(loss_static.detach()))
     assert np.allclose(got, eager, rtol=2e-4, atol=1e-5), (got, eager)
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg4", "cfg2w"])
+def test_bench_line_of_the_other_workloads(workload, gpu_device):
+    """`python bench.py --workload W` end to end for BASELINE.json's other configurations: one JSON line with `roofline` and a `cpu_baseline` whose
+    time-step loop also works when a time step takes microseconds (round 6: the budget loop divided by a rounded-to-zero duration on cfg3)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "10", "--warmup", "3"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["value"] > 0 and line["n_gpus"] == 1 and line["roofline"]["frac"] > 0 and "other_workloads" not in line
+    cpu = line["cpu_baseline"]
+    assert cpu["value"] > 0 and cpu["gpu_vs_cpu_rel_err"] <= 1e-5 and cpu["scaled_from"] is None and cpu["host"]["os_cpu_count"] >= 1
+    assert len(cpu["samples_timed"]) == {"cfg3": 64, "cfg4": 1, "cfg2w": 128}[workload]
+    if workload != "cfg4":
+        assert cpu["torch_dense_einsum"]["gpu_vs_cpu_rel_err"] <= 1e-5

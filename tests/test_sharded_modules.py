@@ -294,3 +294,71 @@ def test_parameters_follow_the_groups_first_rank():
     res = _spawn(_sync_init_worker, 3)
     assert all(r[0] for r in res) and res[0][1] and not res[1][1] and not res[2][1]
     assert all(r[2] == 0 and r[3] == 0 for r in res)
+
+
+def _model_worker(rank, world, port, ret):
+    """a two-layer model written like the reference's (pytorch_hcp_tgcn.py:100-141: TGCNCheb_H -> relu -> GCNCheb -> relu -> head), its Chebyshev
+    layers sharded: three SGD steps against the SAME model in one process on the whole graph (the single-GPU modules' arithmetic is replaced by
+    float64 torch here -- this is the CPU suite -- so the comparison is sharded control flow + all-reduced gradients against plain autograd)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import scipy.sparse as sp
+        from tgcn_amd import dist as tdist
+        n, q, H, g1, g2, K = 160, 3, 12, 5, 4, 3
+        row, col, val = _graph(n, 23, True)
+        Lsp = sp.coo_matrix((val, (row, col)), shape=(n, n)).tocsr()
+        torch.manual_seed(7)
+        l1 = tdist.ShardedTGCNCheb_H(Lsp, 1, g1, K, H, ops=CpuOps(), exchange="halo")
+        l2 = tdist.ShardedGCNCheb(Lsp, g1, g2, K, ops=CpuOps(), exchange="auto")
+        params = list(l1.parameters()) + list(l2.parameters())
+        # the same model on the whole graph, float64 dense autograd, from the same parameters
+        Ld = torch.tensor(Lsp.toarray(), dtype=torch.float64)
+        ref_p = [p.detach().double().clone().requires_grad_(True) for p in params]
+
+        def cheb(x3, W, b):                    # dense-L classes' recursion (tgcn/nn/gcn.py:63-79)
+            Xt, P = [x3], x3
+            for k in range(1, W.shape[0]):
+                P = torch.einsum("nm,qmc->qnc", Ld, P)
+                Xt.append(P if k == 1 else 2 * P - Xt[k - 2])
+            return sum(Xt[k] @ W[k] for k in range(W.shape[0])) + b
+        rng = np.random.default_rng(24)
+        x = torch.as_tensor(rng.standard_normal((q, n, H)))
+        y = torch.as_tensor(rng.standard_normal((q, n, g2)))
+        lo, hi = l1.owned_rows("cpu")
+        assert (lo, hi) == l2.owned_rows("cpu")
+        losses = []
+        for step in range(3):
+            for p in params:
+                p.grad = None
+            h = torch.relu(l1(x[:, lo:hi].float()))
+            out = l2(h)
+            # mean over ALL vertices: every rank adds its rows' share; the gradient of the global loss w.r.t. the replicated parameters is the
+            # all-reduced sum the layers produce
+            loss_local = ((out - y[:, lo:hi].float()) ** 2).sum() / (q * n * g2)
+            loss_local.backward()
+            tot = loss_local.detach().clone()
+            dist.all_reduce(tot)
+            for rp in ref_p:
+                rp.grad = None
+            W1, b1, W2, b2 = ref_p
+            hr = torch.relu(cheb(x, W1.reshape(K, H, g1), b1.reshape(1, n, g1)))
+            lr = ((cheb(hr, W2, b2.reshape(1, 1, g2)) - y) ** 2).mean()
+            lr.backward()
+            errs = [_rel(p.grad.numpy(), rp.grad.numpy()) for p, rp in zip(params, ref_p)]
+            losses.append((float(tot), float(lr), max(errs)))
+            with torch.no_grad():
+                for p, rp in zip(params, ref_p):
+                    p -= 0.5 * p.grad
+                    rp -= 0.5 * rp.grad
+        ret[rank] = losses
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_sharded_layers_train_like_the_whole_graph_model():
+    res = _spawn(_model_worker, 3)
+    for losses in res:
+        for tot, ref, gerr in losses:
+            assert abs(tot - ref) <= 1e-5 * abs(ref) and gerr <= 5e-5, losses
+        assert losses[2][0] < losses[0][0]                      # and the steps do reduce the loss

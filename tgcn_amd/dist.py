@@ -305,6 +305,7 @@ class VertexShardedCheb:
             T = VertexShardedCheb._from_owned(self.n, self.bounds, rT, cT, vT, self.group, self.device, self._exchange_arg, self.ops)
             T._T = self
             self._T = T
+            self._entries = T._entries = None          # both directions exist now: the global-id copies of the owned entries (20 bytes each) can go
         return self._T
 
     # ------------------------------------------------------------------ buffers
