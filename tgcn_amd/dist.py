@@ -37,6 +37,8 @@ tests/test_sharded_modules.py: overlapped against non-overlapped form bit for bi
 import torch
 import torch.distributed as dist
 
+from . import nn as _nn
+
 PROJECT_FIRST = True      # developer switch: project first inside a shard when the output is at most half as wide as an input row
 
 
@@ -686,49 +688,45 @@ class _ShardedMixin:
         return ShardedChebFn.apply(x3, W_kcn, bias_local, sh, mode, bias_kind if self.bias is not None else 0, self._grad_group, self.overlap, self.depth)
 
 
-def _sharded_class(base, doc):
-    from . import nn as _nn
+class _Sharded(_ShardedMixin):
+    """constructor of the single-GPU class (the reference's arguments) + the sharding keywords; forward on the owned rows"""
 
-    class Sharded(_ShardedMixin, getattr(_nn, base)):
-        def __init__(self, *args, group=None, exchange="auto", ops=None, sync_bias_grad=True, grad_group=None, sync_init=True, bounds=None,
-                     row_multiple=1, **kw):
-            getattr(_nn, base).__init__(self, *args, **kw)
-            self._init_sharding(group, exchange, ops, sync_bias_grad, grad_group, sync_init, bounds, row_multiple)
-
-        def forward(self, x_local):
-            if self._single_gpu():
-                return getattr(_nn, base).forward(self, x_local)
-            if base == "TGCNCheb_H":
-                if x_local.dim() == 3:
-                    x_local = x_local.unsqueeze(3)
-                q, rows, h, f = x_local.shape
-                x3 = x_local.float().reshape(q, rows, h * f)
-                W = self.weight.reshape(self.weight.shape[0], h * f, self.out_channels)
-                return self._sharded_layer(x3, W, 2)
-            if base == "GCNCheb":
-                if x_local.dim() == 2:
-                    x_local = x_local.unsqueeze(2)
-                return self._sharded_layer(x_local.float(), self.weight, 1)
-            return self._sharded_layer(x_local.float(), self.weight, 2)
-
-    Sharded.__name__ = Sharded.__qualname__ = "Sharded" + base
-    Sharded.__doc__ = doc
-    return Sharded
+    def __init__(self, *args, group=None, exchange="auto", ops=None, sync_bias_grad=True, grad_group=None, sync_init=True, bounds=None,
+                 row_multiple=1, **kw):
+        super().__init__(*args, **kw)
+        self._init_sharding(group, exchange, ops, sync_bias_grad, grad_group, sync_init, bounds, row_multiple)
 
 
-_CLASSES = {}
+
+class ShardedTGCNCheb(_Sharded, _nn.TGCNCheb):
+    """tgcn/nn/gcn.py:8-79 vertex-sharded: x_local (q, owned, f) -> (q, owned, g); weight (K, f, g), bias (1, n, g) with their GLOBAL shapes."""
+
+    def forward(self, x_local):
+        if self._single_gpu():
+            return _nn.TGCNCheb.forward(self, x_local)
+        return self._sharded_layer(x_local.float(), self.weight, 2)
 
 
-def __getattr__(name):
-    """ShardedTGCNCheb / ShardedTGCNCheb_H / ShardedGCNCheb are built on first use (they subclass tgcn_amd.nn's modules, which this
-    module must not import at load time: nn imports nothing from here, but the package imports both)."""
-    docs = {
-        "ShardedTGCNCheb": "tgcn/nn/gcn.py:8-79 vertex-sharded: x_local (q, owned, f) -> (q, owned, g); weight (K, f, g), bias (1, n, g) global.",
-        "ShardedTGCNCheb_H": "tgcn/nn/gcn.py:82-154 vertex-sharded: x_local (q, owned, h[, f]) -> (q, owned, g); weight (K, H, f, g), bias (1, n, g) global.",
-        "ShardedGCNCheb": "tgcn/nn/gcn.py:158-237 vertex-sharded: x_local (q, owned[, f]) -> (q, owned, g); weight (K, f, g), bias (1, 1, g).",
-    }
-    if name in docs:
-        if name not in _CLASSES:
-            _CLASSES[name] = _sharded_class(name[len("Sharded"):], docs[name])
-        return _CLASSES[name]
-    raise AttributeError("module %r has no attribute %r" % (__name__, name))
+class ShardedTGCNCheb_H(_Sharded, _nn.TGCNCheb_H):
+    """tgcn/nn/gcn.py:82-154 vertex-sharded: x_local (q, owned, h[, f]) -> (q, owned, g); weight (K, H, f, g), bias (1, n, g) global.  With a long
+    horizon and few output channels (examples/pytorch_based/pytorch_hcp_tgcn.py:103-104) the shard projects first: hops and halo messages on g-wide rows."""
+
+    def forward(self, x_local):
+        if self._single_gpu():
+            return _nn.TGCNCheb_H.forward(self, x_local)
+        if x_local.dim() == 3:
+            x_local = x_local.unsqueeze(3)
+        q, rows, h, f = x_local.shape
+        W = self.weight.reshape(self.weight.shape[0], h * f, self.out_channels)
+        return self._sharded_layer(x_local.float().reshape(q, rows, h * f), W, 2)
+
+
+class ShardedGCNCheb(_Sharded, _nn.GCNCheb):
+    """tgcn/nn/gcn.py:158-237 vertex-sharded: x_local (q, owned[, f]) -> (q, owned, g); weight (K, f, g), bias (1, 1, g)."""
+
+    def forward(self, x_local):
+        if self._single_gpu():
+            return _nn.GCNCheb.forward(self, x_local)
+        if x_local.dim() == 2:
+            x_local = x_local.unsqueeze(2)
+        return self._sharded_layer(x_local.float(), self.weight, 1)
