@@ -367,7 +367,7 @@ def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, r
     ShardedTGCNCheb_H: the reference's constructor arguments + a process group; weight fold, project-first and the exchange inside): every
     rank holds the seeded graph, owns an nnz-balanced row range (inside its group of `vertex_shards` ranks for mode "hybrid"; the groups
     split the q_total time steps, no communication between them) and its slice of x.
-    -> (callable(overlap, qs), VertexShardedCheb, groups, time steps of this group, the module)"""
+    -> (callable(overlap, qs), VertexShardedCheb, groups, time steps of this group, the module, this rank's x)"""
     from tgcn_amd import dist as tdist
     assert spec["cls"] in ("TGCNCheb", "TGCNCheb_H"), "vertex sharding bench is wired for the cfg5 / cfg4 layers"
     group, gi, ngroups = None, 0, 1
@@ -399,7 +399,7 @@ def build_sharded(op, spec, q_total, device, rank, world, mode, vertex_shards, r
         # qs: only the first qs of the group's time steps (the extras size themselves to their budget; columns are independent)
         layer.overlap = overlap
         return layer(x_local if qs is None else x_local[:qs])
-    return fwd, sh, ngroups, q, layer
+    return fwd, sh, ngroups, q, layer, x_local
 
 
 class Progress:
@@ -470,7 +470,7 @@ def run_extras(op, spec, q_total, device, rank, world, args, sync_all, dist, pro
     for mi, (mode, vs) in enumerate(modes):
         try:
             progress.enter("%s: building shards" % mode)
-            fwd, sh, ngroups, qg, _ = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs, rehearsal, args.extras_exchange)
+            fwd, sh, ngroups, qg, _, _ = build_sharded(op, dict(spec), q_total, device, rank, world, mode, vs, rehearsal, args.extras_exchange)
         except Exception as e:      # noqa: BLE001 -- reported, never fatal
             import traceback
             traceback.print_exc()
@@ -642,6 +642,16 @@ def main():
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # started by torch.distributed.run (the driver's N > 1 command, or self_launch)
     if args.gpus > 1 and not launched:
         sys.exit(self_launch(args))          # parent: no GPU call has been made in this process, and none will be
+    if not launched and args.shard in ("vertex", "hybrid"):
+        # `python bench.py --workload cfg4 --shard vertex` on one GPU: the sharded layer needs a process group also at world size 1 (its
+        # collectives run on the real backend with one rank) -- this process becomes that rank instead of quietly measuring the single-GPU driver
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        s_.close()
+        launched = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -687,14 +697,9 @@ def main():
     vertex_mode = dist is not None and args.shard in ("vertex", "hybrid")       # world 1 under a launcher: the same code on one rank (first contact with RCCL)
     ngroups = 1
     if vertex_mode:
-        fwd, sh, ngroups, q, sharded_module = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards, rehearsal, args.extras_exchange)
-        spec["q"] = q
-
-        class _Sharded:
-            bias = sharded_module.bias
-            def __call__(self, _x):
-                return fwd()
-        layer, x = _Sharded(), None
+        fwd, sh, ngroups, q, layer, x = build_sharded(op, spec, q_total, device, rank, world, args.shard, args.vertex_shards, rehearsal, args.extras_exchange)
+        spec["q"] = q          # the module itself is stepped: layer(x_local) -> out_local (overlapped form); at world 1 its rows are the whole graph,
+                               # so the CPU leg below checks it against the oracle like the single-GPU layer
     elif rehearsal:
         layer = _CpuLayer(op, spec)
         x = make_input(op, spec, device, seed=rank)
@@ -845,7 +850,7 @@ def main():
                                       note="SURVEY 8(d) recursion bytes of one rank's forward / its whole forward time (hops + fix-up + projection)")
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not (vertex_mode and rehearsal):
         # first AND last sample: the last one sits behind (q-1)*n*C elements (> 2^31 on cfg5), so the check also covers the
         # 64-bit address arithmetic of the run that was timed
         check = [0, q - 1] if (q > 1 and op.n * C_row * q >= 2 ** 31) else [0]

@@ -142,3 +142,13 @@ def test_the_drivers_eight_rank_command_on_the_cpu():
             assert sum(rk["owned_rows"] for rk in e["ranks"]) == 4 * 4000          # every group holds the whole graph
         else:
             assert sum(rk["owned_rows"] for rk in e["ranks"]) == 4000
+
+
+def test_shard_vertex_without_a_launcher_is_the_sharded_layer_on_one_rank():
+    """`python bench.py --workload cfg4 --shard vertex` used to fall through to the single-GPU driver when no launcher had set
+    WORLD_SIZE: the process now forms a one-rank group itself and runs the vertex-sharded MODULE (here: CPU rehearsal, gloo, stand-in arithmetic)"""
+    r = _bare(["--rehearsal-cpu", "--workload", "cfg4", "--shard", "vertex", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1
+    assert lines[0]["config"]["sharding"].startswith("vertex rows across ranks") and lines[0]["config"]["dist_backend"] == "gloo"

@@ -295,3 +295,22 @@ def test_vertex_sharded_two_ranks_two_gpus_rccl(exchange, banded):
     assert len(ret) == world and sum(ret[r][2] for r in range(world)) == 3000
     for r in range(world):
         assert ret[r][0] <= 1e-5 and ret[r][1] == exchange and ret[r][3], ret[r]
+
+
+def test_bench_cfg4_shard_vertex_line_without_a_launcher(gpu_device):
+    """`python bench.py --workload cfg4 --shard vertex`: the process forms a one-rank RCCL group itself, steps the sharded MODULE
+    (project-first inside, 32-float hop rows) and checks its output against oracle/cheb_ref.c like the single-GPU line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg4", "--shard", "vertex", "--steps", "5", "--warmup", "2"], cwd=root,
+                       env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["config"]["dist_backend"] == "nccl" and line["config"]["sharding"].startswith("vertex rows across ranks")
+    assert line["roofline"]["path"].startswith("project-first") and line["roofline"]["launches_per_step"] == 4
+    assert line["cpu_baseline"]["gpu_vs_cpu_rel_err"] <= 1e-5

@@ -207,6 +207,9 @@ class VertexShardedCheb:
             self.bounds = torch.as_tensor(bounds, dtype=torch.int64).to(self.device)
             assert self.bounds.numel() == self.world + 1 and int(self.bounds[0]) == 0 and int(self.bounds[-1]) == self.n
         b = self.bounds.tolist()
+        if any(b[i + 1] <= b[i] for i in range(self.world)):
+            # every rank sees the same bounds, so every rank raises: no rank is left waiting in a collective
+            raise ValueError("vertex sharding over %d ranks leaves a rank without rows (bounds %s): fewer shards, or pass bounds=" % (self.world, b))
         self.lo, self.hi = b[self.rank], b[self.rank + 1]
         mine = (row >= self.lo) & (row < self.hi)
         self._exchange_arg = exchange
