@@ -976,8 +976,10 @@ def test_bf16x3_margin_at_k25_with_growing_terms(variant, gpu_device):
     """the MARGIN of the bf16x3 projection, pinned where it is thinnest -- K = 25 of the dense-L classes' recursion
     (Xt[k] = 2 L^k x - Xt[k-2]: the folded weights W'_j = sum_k c[k, j] W_k carry coefficients of both signs up to 2 that cancel in the
     sum over the 25 monomial terms), 8,281 vertices x 2 samples = 16,562 rows (>= 8192: the shipped choice IS the bf16x3 kernel), 64 -> 64
-    channels.  Against the float64 evaluation of the reference's own unfolded recursion: <= 5e-6, half the 1e-5 bar (variant 4, exact
-    fp32 MFMA, for comparison under the same bound)."""
+    channels.  Against the float64 evaluation of the reference's own unfolded recursion: <= 3e-6 (variant 4, exact fp32 MFMA, for comparison
+    under the same bound).  Round 6 measured the curve (tools/k_margin.py, profiles/r06_k_margin.jsonl): 0.9e-6 at K = 5, 1.8e-6 at 25, 2.2e-6 at
+    32, 2.3e-6 at 48, 1.8e-6 at 64 -- flat in K, the bf16x3 split at or BELOW the exact-fp32 kernel (2.5e-6 at 25) -- so the pin moves from 5e-6 to
+    3e-6: a factor 3 under the 1e-5 bar that does not shrink with the filter order (the reference's own fp32 evaluation order is at 2.6e-7)."""
     import tgcn_amd
     from tgcn_amd import _lib
     from tools import synth
@@ -1001,4 +1003,4 @@ def test_bf16x3_margin_at_k25_with_growing_terms(variant, gpu_device):
     with torch.no_grad():
         out = layer(_dev(x))
     err = rel_err(out.cpu().numpy(), ref)
-    assert err <= 5e-6, (variant, err, growth)
+    assert err <= 3e-6, (variant, err, growth)
