@@ -257,11 +257,19 @@ MFMA_F32_PEAK_TFLOPS = 157.3        # fp32 matrix peak
 
 
 def other_workload_entry(name, device, steps=20, warmup=5):
-    """One of BASELINE.json's other configurations (cfg2 f = 1 / 64, cfg3, cfg4) in the driver's record: ms per forward,
-    the roofline of ITS dominant kernel from the library's launch events, and the GPU result against the CPU restatements."""
+    """One of BASELINE.json's other configurations (cfg2 f = 1 / 64, cfg3, cfg4; the headline's R-MAT with degree-sorted labels) in the driver's
+    record: ms per forward, the roofline of ITS dominant kernel from the library's launch events, and the GPU result
+    against the CPU restatements."""
     from tgcn_amd import _lib, functional as _F
     t_start = time.perf_counter()
-    op, spec = build_workload(name, "natural", device)
+    big = name.startswith("cfg5")
+    if name == "cfg5_degree":
+        # SURVEY.md 8(d) asks for BOTH labelings of the R-MAT; the headline is the random (worst-case) one, this is the degree-sorted ("friendly")
+        # one -- which is the SLOWER of the two on this kernel (DESIGN.md section 6: the hot rows share few L2 / memory channels)
+        op, spec = build_workload("cfg5", "degree", device)
+        steps, warmup = 3, 1
+    else:
+        op, spec = build_workload(name, "natural", device)
     layer = make_layer(op, spec, device)
     x = make_input(op, spec, device, seed=0)
     K, q, H = spec["K"], spec["q"], spec["H"]
@@ -273,10 +281,13 @@ def other_workload_entry(name, device, steps=20, warmup=5):
         # three rounds of `steps` forwards, the best one reported (all three kept in `rounds_ms`): these configurations take 40 ... 350 us per
         # forward, and the first round after the 150 GB of the headline were handed back to the driver has been seen 20 x slower than the next
         rounds = []
-        for _ in range(3):
+        for _ in range(1 if big else 3):
+            out = None                     # (one output buffer at a time: 41 GB on the R-MAT)
             _lib.profile_start(8192)
             t0 = time.perf_counter()
             for _ in range(steps):
+                if big:
+                    out = None
                 out = layer(x)
             torch.cuda.synchronize()
             rounds.append((time.perf_counter() - t0, _lib.profile_stop(8192)))
@@ -323,8 +334,10 @@ def other_workload_entry(name, device, steps=20, warmup=5):
         entry["hop_roofline"] = dict(bound="hbm", achieved=round(bytes_recursion / n_l / (mean_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                                      frac=round(bytes_recursion / n_l / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), launches_per_step=n_l, mean_launch_ms=round(mean_ms, 4),
                                      path="project-first (hops on C_out-wide rows)" if pf else "hops-first")
-    ref_out, cpu = cpu_baseline(op, spec, layer, x, samples=range(q))
-    err = float(np.abs(out.cpu().numpy() - ref_out).max() / np.abs(ref_out).max())
+    check = [q - 1] if big else list(range(q))          # the R-MAT: one time step (the last: beyond 2^31 elements into x and out), ~11 s of CPU
+    ref_out, cpu = cpu_baseline(op, spec, layer, x, samples=check)
+    got = np.stack([out[i].cpu().numpy() for i in check])
+    err = float(np.abs(got - ref_out).max() / np.abs(ref_out).max())
     entry["gpu_vs_cpu_rel_err"] = err
     entry["cpu_baseline"] = dict(value=round(cpu["value"], 4), unit=cpu["unit"], cores=cpu["cores"], kind="port", sample=cpu["sample"], seconds=round(cpu["seconds"], 3))
     assert err <= 1e-5, "%s: GPU result differs from the CPU restatement: %g" % (name, err)
@@ -951,7 +964,7 @@ def main():
             plan = plan_r = None
             torch.cuda.empty_cache()
             others = []
-            for name in ("cfg2", "cfg2w", "cfg3", "cfg4"):
+            for name in ("cfg5_degree", "cfg2", "cfg2w", "cfg3", "cfg4"):
                 try:
                     others.append(other_workload_entry(name, device))
                 except Exception as e:      # noqa: BLE001
