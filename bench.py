@@ -84,7 +84,7 @@ def build_workload(name, labeling, device, n_override=None, nnz_override=None):
     else:
         raise SystemExit("unknown workload " + name)
     # one-off operand construction, timed for the record (not part of a step): COO -> CSR, then the hop schedule of the layer's row width
-    from tgcn_amd import graph as _graph, _lib as _l
+    from tgcn_amd import graph as _graph
     sync = (lambda: torch.cuda.synchronize()) if torch.device(device).type == "cuda" else (lambda: None)
     if torch.device(device).type == "cuda" and n * 8 < (1 << 31):
         # untimed first build: the caching allocator obtains its blocks from the driver (a cold hipMalloc of gigabytes takes ~0.1 s)

@@ -314,3 +314,55 @@ def test_bench_cfg4_shard_vertex_line_without_a_launcher(gpu_device):
     assert line["n_gpus"] == 1 and line["config"]["dist_backend"] == "nccl" and line["config"]["sharding"].startswith("vertex rows across ranks")
     assert line["roofline"]["path"].startswith("project-first") and line["roofline"]["launches_per_step"] == 4
     assert line["cpu_baseline"]["gpu_vs_cpu_rel_err"] <= 1e-5
+
+
+def _edge_module_worker(rank, world, port, timed, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tgcn_amd import dist as tdist
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(41)
+        n, E, q, f, g_ch, K, H = 4000, 30000, 2, 8, 6, 4, 5
+        ei = rng.integers(0, n, (2, E))
+        ei[1, : E // 10] = ei[0, : E // 10]
+        w = rng.uniform(0.5, 1.5, E).astype(np.float32)
+        edge_index, edge_weight = torch.as_tensor(ei).to(dev), torch.as_tensor(w).to(dev)
+        torch.manual_seed(9)
+        if timed:
+            mod = tdist.ShardedChebTimeConv(1, g_ch, K, H).to(dev)
+            x = rng.standard_normal((q, n, H)).astype(np.float32)
+            fwd = O.cheb_time_conv_forward
+        else:
+            mod = tdist.ShardedChebConv(f, g_ch, K).to(dev)
+            x = rng.standard_normal((q, n, f)).astype(np.float32)
+            fwd = O.cheb_conv_forward
+        lo, hi = mod.owned_rows(dev, edge_index, n, edge_weight)
+        xl = torch.as_tensor(np.ascontiguousarray(x[:, lo:hi])).to(dev).requires_grad_(True)
+        out = mod(xl, edge_index, edge_weight)
+        gout = rng.standard_normal((q, n, g_ch)).astype(np.float32)
+        out.backward(torch.as_tensor(np.ascontiguousarray(gout[:, lo:hi])).to(dev))
+        W, b = mod.weight.detach().cpu().numpy(), mod.bias.detach().cpu().numpy()
+        ref = fwd(x, ei, w, W, b)
+        r_, c_, lap = O.edge_laplacian(ei, w, n)
+        xr = x if not timed else x[..., None]
+        rx, rW = O.layer_backward(O.coo_to_csr(r_, c_, lap, n), xr, W, gout, "chebyshev")
+        rx = rx.reshape(x.shape)
+        rel = lambda a, b_, full: float(np.abs(a - b_).max() / np.abs(full).max())          # noqa: E731
+        ret[rank] = (rel(out.detach().cpu().numpy(), ref[:, lo:hi], ref), rel(xl.grad.cpu().numpy(), rx[:, lo:hi], rx),
+                     rel(mod.weight.grad.cpu().numpy(), rW, rW), rel(mod.bias.grad.cpu().numpy(), gout.astype(np.float64).sum((0, 1)), gout.astype(np.float64).sum((0, 1))), hi - lo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("timed", [False, True])
+def test_sharded_edge_list_modules_hip_two_ranks_one_gpu(timed, gpu_device):
+    """ShardedChebConv / ShardedChebTimeConv with the library's edge normalisation and the HIP kernels, two ranks on one GPU"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_edge_module_worker, args=(world, _free_port(), timed, ret), nprocs=world, join=True)
+    assert len(ret) == world and sum(ret[r][4] for r in range(world)) == 4000
+    for r in range(world):
+        assert ret[r][0] <= 1e-5 and max(ret[r][1:4]) <= 2e-5, ret[r]

@@ -362,3 +362,62 @@ def test_two_sharded_layers_train_like_the_whole_graph_model():
         for tot, ref, gerr in losses:
             assert abs(tot - ref) <= 1e-5 * abs(ref) and gerr <= 5e-5, losses
         assert losses[2][0] < losses[0][0]                      # and the steps do reduce the loss
+
+
+# ------------------------------------------------------------------------------------------------ edge-list classes
+def _edge_worker(rank, world, port, ret, timed, weighted):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import tgcn_amd
+        from tgcn_amd import dist as tdist
+        rng = np.random.default_rng(31)
+        n, E, q, f, g_ch, K, H = 220, 1500, 2, 3, 4, 4, 5
+        ei = rng.integers(0, n, (2, E))
+        ei[1, : E // 10] = ei[0, : E // 10]                      # self loops (removed, gcn.py:398)
+        ei[:, E // 2: E // 2 + 100] = ei[:, :100]                # duplicate edges (separate terms)
+        ei[0][ei[0] == 17] = 18                                  # vertex 17 has no outgoing edge: degree 0 -> deg^-1/2 = 0
+        w = rng.uniform(0.5, 1.5, E).astype(np.float32) if weighted else None
+        edge_index = torch.as_tensor(ei)
+        edge_weight = None if w is None else torch.as_tensor(w)
+        torch.manual_seed(3)
+        if timed:
+            single = tgcn_amd.ChebTimeConv(f, g_ch, K, H)
+            x = rng.standard_normal((q, n, H, f)).astype(np.float32)
+            torch.manual_seed(50 + rank)
+            mod = tdist.ShardedChebTimeConv(f, g_ch, K, H, ops=CpuOps(), exchange="halo")
+            fwd = O.cheb_time_conv_forward
+        else:
+            single = tgcn_amd.ChebConv(f, g_ch, K)
+            x = rng.standard_normal((q, n, f)).astype(np.float32)
+            torch.manual_seed(50 + rank)
+            mod = tdist.ShardedChebConv(f, g_ch, K, ops=CpuOps(), exchange="auto")
+            fwd = O.cheb_conv_forward
+        mod.load_state_dict(single.state_dict())
+        lo, hi = mod.owned_rows("cpu", edge_index, n, edge_weight)
+        xl = torch.from_numpy(np.ascontiguousarray(x[:, lo:hi])).requires_grad_(True)
+        out = mod(xl, edge_index, edge_weight)                   # the cached shard of this edge_index: no num_vertices needed any more
+        gout = rng.standard_normal((q, n, g_ch)).astype(np.float32)
+        out.backward(torch.from_numpy(np.ascontiguousarray(gout[:, lo:hi])))
+        W, b = single.weight.detach().numpy(), single.bias.detach().numpy()
+        ref = fwd(x, ei, w, W, b)
+        r_, c_, lap = O.edge_laplacian(ei, w, n)
+        rx, rW = O.layer_backward(O.coo_to_csr(r_, c_, lap, n), x, W, gout, "chebyshev")
+        ret[rank] = (float(np.abs(out.detach().numpy() - ref[:, lo:hi]).max() / np.abs(ref).max()),
+                     float(np.abs(xl.grad.numpy() - rx[:, lo:hi]).max() / np.abs(rx).max()), _rel(mod.weight.grad.numpy(), rW),
+                     _rel(mod.bias.grad.numpy(), gout.astype(np.float64).sum((0, 1))), lo, hi, len(mod._edge_shards))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,timed,weighted", [(2, False, False), (3, True, True), (2, True, False), (3, False, True)])
+def test_sharded_edge_list_modules(world, timed, weighted):
+    """ShardedChebConv / ShardedChebTimeConv (tgcn/nn/gcn.py:348-538; callers pygeo_hcp.py:85,129): global edge_index on every rank, self loops,
+    duplicate edges, a degree-0 source, optional weights; output and all gradients against the oracle; one cached shard per edge_index"""
+    res = _spawn(_edge_worker, world, timed, weighted)
+    covered = np.zeros(220, np.int32)
+    for e_out, e_x, e_W, e_b, lo, hi, nshards in res:
+        assert e_out <= TOL and e_x <= GRAD_TOL and e_W <= GRAD_TOL and e_b <= GRAD_TOL, (e_out, e_x, e_W, e_b)
+        assert nshards == 1
+        covered[lo:hi] += 1
+    assert np.all(covered == 1)

@@ -91,6 +91,13 @@ class HipOps:
         from .graph import GraphOperand
         return GraphOperand.from_coo(n_rows, row, col, val, device, n_cols=n_cols)
 
+    def edge_coo(self, edge_index, edge_weight, n, device):
+        """(row, col, lap) of the edge-list classes' operand (tgcn/nn/gcn.py:398-413, :495-510: self loops removed, unweighted source degree,
+        lap_e = -deg^-1/2[row] w_e deg^-1/2[col]) through the library's edge normalisation kernels"""
+        from .graph import GraphOperand
+        w = None if edge_weight is None else edge_weight.detach()
+        return GraphOperand.from_edge_index(edge_index, w, n, device).coo()
+
     def hop(self, op, x, z, alpha, beta, out, z2=None, gamma=0.0):
         from . import functional as F
         return F.csr_hop(op, x, z=z, alpha=alpha, beta=beta, out=out, z2=z2, gamma=gamma)
@@ -664,14 +671,19 @@ class _ShardedMixin:
             n, row, col, val = _coo_of(self.L, device)
             sh = self._shards[str(device)] = VertexShardedCheb(n, row, col, val, group=self._group, device=device, exchange=self._exchange,
                                                                ops=self._shard_ops, bounds=self._bounds, row_multiple=self._row_multiple)
-            if self._sync_init and sh.world > 1:
-                src = sh.peer[0]
-                for p in self.parameters():
-                    t = p.data if p.data.device == sh.comm_device else p.data.to(sh.comm_device)
-                    dist.broadcast(t, src=src, group=self._group)
-                    if t is not p.data:
-                        p.data.copy_(t)
+            self._broadcast_parameters(sh)
         return sh
+
+    def _broadcast_parameters(self, sh):
+        """once per module: every rank takes the parameters of the group's first rank (nn.DataParallel replicates device 0's, pytorch_hcp_tgcn.py:271)"""
+        if self._sync_init and sh.world > 1 and not getattr(self, "_params_synced", False):
+            src = sh.peer[0]
+            for p in self.parameters():
+                t = p.data if p.data.device == sh.comm_device else p.data.to(sh.comm_device)
+                dist.broadcast(t, src=src, group=self._group)
+                if t is not p.data:
+                    p.data.copy_(t)
+        self._params_synced = True
 
     def owned_rows(self, device):
         sh = self.shard(device)
@@ -680,8 +692,8 @@ class _ShardedMixin:
     def _single_gpu(self):
         return self._shard_ops is None and not self.force_sharded and (not dist.is_initialized() or dist.get_world_size(self._group) == 1)
 
-    def _sharded_layer(self, x3, W_kcn, bias_kind, mode=0):
-        sh = self.shard(x3.device)
+    def _sharded_layer(self, x3, W_kcn, bias_kind, mode=0, sh=None):
+        sh = self.shard(x3.device) if sh is None else sh
         bias_local = None
         if self.bias is not None:
             if bias_kind == 2:
@@ -733,3 +745,76 @@ class ShardedGCNCheb(_Sharded, _nn.GCNCheb):
         if x_local.dim() == 2:
             x_local = x_local.unsqueeze(2)
         return self._sharded_layer(x_local.float(), self.weight, 1)
+
+
+# ---- the edge-list classes (tgcn/nn/gcn.py:348-538): the graph arrives with every forward
+class _ShardedEdge(_ShardedMixin):
+    """ChebConv / ChebTimeConv vertex-sharded (examples/pytorch_geo_based/pygeo_hcp.py:85,129 call them as conv(x, edge_index); :475-477 wraps the
+    model for several GPUs).  Every rank passes the same GLOBAL edge_index (and edge_weight); the shard of a graph -- operand values by the
+    library's edge normalisation, partition, halo lists -- is built collectively the first time that edge_index is seen and kept (least recently
+    used of 4: pygeo_hcp.py:284 swaps the graph per subject).  The vertex count is not in x_local: ask `owned_rows(device, edge_index,
+    num_vertices)` first (it builds the shard), slice x, then call forward.  A learnable edge_weight is refused (its gradient lives in the
+    single-GPU layer function)."""
+
+    MAX_SHARDS = 4
+
+    def __init__(self, *args, group=None, exchange="auto", ops=None, grad_group=None, sync_init=True, row_multiple=1, **kw):
+        super().__init__(*args, **kw)
+        self._init_sharding(group, exchange, ops, True, grad_group, sync_init, None, row_multiple)
+        import collections
+        self._edge_shards = collections.OrderedDict()
+
+    @staticmethod
+    def _key(t):
+        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+    def _edge_shard(self, device, edge_index, edge_weight, num_vertices):
+        if edge_weight is not None and edge_weight.requires_grad:
+            raise ValueError("sharded edge-list layers take fixed edge weights (detach() them); the gradient w.r.t. edge_weight is the single-GPU modules'")
+        device = torch.device(device)
+        key = (self._key(edge_index), self._key(edge_weight), str(device))
+        hit = self._edge_shards.get(key)
+        if hit is not None:
+            self._edge_shards.move_to_end(key)
+            return hit[0]
+        if num_vertices is None:
+            raise ValueError("first use of this edge_index: pass num_vertices (the x of a shard holds the owned rows only) -- owned_rows(device, edge_index, n)")
+        ops = _HIP_OPS if self._shard_ops is None else self._shard_ops
+        row, col, val = ops.edge_coo(edge_index, edge_weight, int(num_vertices), device)
+        sh = VertexShardedCheb(int(num_vertices), row, col, val, group=self._group, device=device, exchange=self._exchange, ops=self._shard_ops,
+                               row_multiple=self._row_multiple)
+        self._broadcast_parameters(sh)
+        self._edge_shards[key] = (sh, edge_index, edge_weight)          # the sources stay alive: their addresses cannot be handed to another graph
+        while len(self._edge_shards) > self.MAX_SHARDS:
+            self._edge_shards.popitem(last=False)
+        return sh
+
+    def owned_rows(self, device, edge_index, num_vertices, edge_weight=None):
+        sh = self._edge_shard(device, edge_index, edge_weight, num_vertices)
+        return sh.lo, sh.hi
+
+
+class ShardedChebConv(_ShardedEdge, _nn.ChebConv):
+    """tgcn/nn/gcn.py:348-442 vertex-sharded: forward(x_local (q, owned[, f]), edge_index (2, E) GLOBAL, edge_weight=None) -> (q, owned, g)."""
+
+    def forward(self, x_local, edge_index, edge_weight=None, num_vertices=None):
+        if self._single_gpu():
+            return _nn.ChebConv.forward(self, x_local, edge_index, edge_weight)
+        sh = self._edge_shard(x_local.device, edge_index, edge_weight, num_vertices)
+        if x_local.dim() < 3:
+            x_local = x_local.unsqueeze(-1)
+        return self._sharded_layer(x_local.float(), self.weight, 1, mode=1, sh=sh)
+
+
+class ShardedChebTimeConv(_ShardedEdge, _nn.ChebTimeConv):
+    """tgcn/nn/gcn.py:445-538 vertex-sharded: forward(x_local (q, owned, h[, f]), edge_index, edge_weight=None) -> (q, owned, g)."""
+
+    def forward(self, x_local, edge_index, edge_weight=None, num_vertices=None):
+        if self._single_gpu():
+            return _nn.ChebTimeConv.forward(self, x_local, edge_index, edge_weight)
+        sh = self._edge_shard(x_local.device, edge_index, edge_weight, num_vertices)
+        if x_local.dim() < 4:
+            x_local = x_local.unsqueeze(-1)
+        q, rows, h, f = x_local.shape
+        W = self.weight.reshape(self.weight.shape[0], h * f, self.out_channels)
+        return self._sharded_layer(x_local.float().reshape(q, rows, h * f), W, 1, mode=1, sh=sh)

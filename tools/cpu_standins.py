@@ -23,6 +23,18 @@ class CpuOps:
     def operand(self, n_rows, n_cols, row, col, val, device):
         return ScipyOperand(n_rows, n_cols, row, col, val)
 
+    def edge_coo(self, edge_index, edge_weight, n, device):
+        """the edge-list classes' operand in numpy (tgcn/nn/gcn.py:398-413): self loops removed, unweighted source degree, inf -> 0"""
+        row, col = edge_index[0].numpy(), edge_index[1].numpy()
+        keep = row != col
+        row, col = row[keep], col[keep]
+        w = np.ones(row.shape[0], np.float32) if edge_weight is None else edge_weight.detach().numpy().astype(np.float32).reshape(-1)[keep]
+        deg = np.bincount(row, minlength=n).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            dis = deg ** np.float32(-0.5)
+        dis[np.isinf(dis)] = 0
+        return torch.from_numpy(row.astype(np.int64)), torch.from_numpy(col.astype(np.int64)), torch.from_numpy((-dis[row] * w * dis[col]).astype(np.float32))
+
     def hop(self, op, x, z, alpha, beta, out, z2=None, gamma=0.0):
         y = np.stack([op.L.dot(x[b].numpy()) for b in range(x.shape[0])]).astype(np.float32)
         y = np.float32(alpha) * y

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 def main():
     import tgcn_amd
-    from tgcn_amd import functional as F, _lib
+    from tgcn_amd import functional as F
     from tools import synth
     dev = torch.device("cuda:0")
     n, row, col, val = synth.sheet_mesh(244, device=dev)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The Z projection of the project-first form (cfg4: 90 k x 1200 x 160) with and without an OUTPUT row map: what the vertex shards' [interior |
 boundary] row order costs the projection (tgcn_cheb_project_first_f32; developer tool)."""
-import os, sys, time, json
+import os, sys, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from tgcn_amd import functional as F, _lib
