@@ -271,7 +271,6 @@ class VertexShardedCheb:
             owner = torch.searchsorted(self.bounds[1:].contiguous(), c, right=True)
             c_local = owner * self.n_max + (c - self.bounds[owner])
             self.n_ext = self.world * self.n_max
-        self.op = ops.operand(self.owned, self.n_ext, r, c_local, v, self.device)
         # ---- overlapped form: owned rows in the order [interior | boundary] -- interior rows have no remote
         # column, so their part of a hop runs while the exchange of the previous hop's cut rows is in flight
         if exchange == "halo":
@@ -297,8 +296,9 @@ class VertexShardedCheb:
             nb = self.owned - self.n_int
             self.op_bnd = ops.operand(nb, self.n_ext, r2[~is_int] - self.n_int, c2[~is_int], v[~is_int], self.device) if nb else None
             # the same rows as one operand (non-overlapped form): identical labels, so both forms sum every row in the same order
-            self.op_all = ops.operand(self.owned, self.n_ext, r2, c2, v, self.device)
+            self.op = self.op_all = ops.operand(self.owned, self.n_ext, r2, c2, v, self.device)
         else:                       # all-gather: every row waits for the gathered operand, one operand serves both forms
+            self.op = ops.operand(self.owned, self.n_ext, r, c_local, v, self.device)
             self.op_int, self.op_bnd, self.op_all = None, self.op, self.op
 
     def transpose(self):
