@@ -298,7 +298,7 @@ def other_workload_entry(name, device, steps=20, warmup=5):
     by_kind = {}
     for kind, ms in prof:
         by_kind.setdefault(kind, []).append(ms)
-    names = {0: "hop_kernel", 1: "hop_fixup_kernel", 2: "projection", 3: "relayout_kernel", 4: "small_forward_kernel"}
+    names = {0: "hop_kernel", 1: "hop_fixup_kernel", 2: "projection", 3: "relayout_kernel", 4: "small_graph_one_launch"}
     entry["kernel_ms_per_step"] = {names.get(k, str(k)): round(float(np.sum(v)) / steps, 4) for k, v in sorted(by_kind.items())}
     dom = max(by_kind, key=lambda k: float(np.sum(by_kind[k]))) if by_kind else None
     pf = _F.use_project_first(q, op.n, C_row, g_ch) and not _F.small_path_tile(op, C_row, 0)
@@ -308,7 +308,7 @@ def other_workload_entry(name, device, steps=20, warmup=5):
         layer_bytes = bytes_recursion + 4 * op.n * q * g_ch + 4 * K * C_row * g_ch + 4 * layer.bias.numel()
         mean_ms = float(np.mean(by_kind[4]))
         ach = layer_bytes / (mean_ms * 1e-3) / 1e9
-        entry["roofline"] = dict(bound="hbm", kernel="small_forward_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
+        entry["roofline"] = dict(bound="hbm", kernel="small_forward_kernel / small_narrow_kernel (the one-launch small-graph kernels)", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
                                  traffic=None, algorithmic_bytes_per_launch=int(layer_bytes), mean_launch_ms=round(mean_ms, 4),
                                  launches_per_step=len(by_kind[4]) // steps,
                                  note="whole layer in one launch (CSR + activations in LDS): latency-bound configuration, BASELINE.md 4 sets no bar")
