@@ -1004,3 +1004,41 @@ def test_bf16x3_margin_at_k25_with_growing_terms(variant, gpu_device):
         out = layer(_dev(x))
     err = rel_err(out.cpu().numpy(), ref)
     assert err <= 3e-6, (variant, err, growth)
+
+
+def test_developer_state_is_per_thread(gpu_device):
+    """VERDICT r05 item 7 (ABI v7): tgcn_set_tuning and the tgcn_profile_* record are thread_local in the library -- the shipped ABI has no
+    process-global mutable state.  A switch set by a worker thread changes THAT thread's launches (another projection kernel:
+    other bits) and nothing in the main thread; a launch-timing record started by the main thread holds the main thread's launches only."""
+    import threading
+    from tgcn_amd import _lib, functional as F
+    from tgcn_amd.graph import GraphOperand
+    rng = np.random.default_rng(77)
+    n = 6000
+    row, col, val = _random_graph(n, 5, rng)
+    op = GraphOperand.from_coo(n, _dev(row), _dev(col), _dev(val))
+    x = _dev(rng.standard_normal((1, n, 64)).astype(np.float32))
+    M, Kc, N = 16384, 64, 64                         # >= 8192 rows and 64 k: the shipped choice is the bf16x3 kernel
+    a = _dev(rng.standard_normal((M, Kc)).astype(np.float32))
+    W = _dev((rng.standard_normal((1, Kc, N)) / 8).astype(np.float32))
+    base = F.cheb_project([a], W, None, 0, M).clone()
+    got = {}
+
+    def worker():
+        torch.cuda.set_device(0)
+        _lib.check(_lib.lib().tgcn_set_tuning(b"project_variant", 4))          # exact-fp32 MFMA for THIS thread
+        got["worker"] = F.cheb_project([a], W, None, 0, M).clone()
+        F.csr_hop(op, x)                                                       # a launch the main thread's record must not see
+        torch.cuda.synchronize()
+    _lib.profile_start(64)
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    again = F.cheb_project([a], W, None, 0, M)                                 # main thread: still the default kernel
+    F.csr_hop(op, x)
+    torch.cuda.synchronize()
+    prof = _lib.profile_stop(64)
+    assert torch.equal(again, base)
+    assert not torch.equal(got["worker"], base) and rel_err(got["worker"].cpu().numpy(), base.cpu().numpy()) <= 2e-6
+    kinds = [k for k, _ in prof]
+    assert kinds.count(0) == 1 and kinds.count(2) == 1, kinds                  # one hop + one projection: the main thread's own
