@@ -1042,3 +1042,45 @@ def test_developer_state_is_per_thread(gpu_device):
     assert not torch.equal(got["worker"], base) and rel_err(got["worker"].cpu().numpy(), base.cpu().numpy()) <= 2e-6
     kinds = [k for k, _ in prof]
     assert kinds.count(0) == 1 and kinds.count(2) == 1, kinds                  # one hop + one projection: the main thread's own
+
+
+@pytest.mark.parametrize("M,Kc,N,T,inter", [(9000, 16, 96, 40, 1), (9600, 64, 128, 2, 3), (8500, 32, 160, 35, 1), (8192, 64, 112, 1, 1)])
+def test_wide_projection_epilogue_accumulate_and_interleave(M, Kc, N, T, inter, gpu_device):
+    """round 6: the wide bf16x3 kernel (>= 96 columns) stores through its LDS vector epilogue -- here with the forms test_project_vs_numpy's
+    wide shapes do not reach: more than 32 terms (a second launch ACCUMULATING onto the first one's output), the vertex-major interleave
+    of the output rows, a column count that is not a multiple of 16; three bias kinds; against float64"""
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(M + N)
+    terms = [rng.standard_normal((M, Kc)).astype(np.float32) for _ in range(T)]
+    W = (rng.standard_normal((T, Kc, N)) / np.sqrt(T * Kc)).astype(np.float32)
+    nv = M // inter
+    for kind, bias in ((0, None), (1, rng.standard_normal(N).astype(np.float32)), (2, rng.standard_normal((nv, N)).astype(np.float32))):
+        ref = sum(t.astype(np.float64) @ w.astype(np.float64) for t, w in zip(terms, W))
+        if inter > 1:
+            ref = ref.reshape(nv, inter, N).transpose(1, 0, 2).reshape(M, N)
+        if kind == 1:
+            ref = ref + bias
+        elif kind == 2:
+            ref = (ref.reshape(-1, nv, N) + bias).reshape(M, N)
+        out = F.cheb_project([_dev(t) for t in terms], _dev(W), None if bias is None else _dev(bias), kind, nv, inter)
+        assert rel_err(out.cpu().numpy(), ref) <= TOL, kind
+
+
+@pytest.mark.parametrize("mapped_terms", [0, 1, 5])
+def test_wide_projection_through_a_row_map(mapped_terms, gpu_device):
+    """the wide kernel with a row map: output rows only (the vertex shards' Z projection: the software-pipelined loop since round 6), term 0
+    mapped (x in the caller's labels next to compact hop tensors), terms 0 and 2 mapped -- output and bias rows through the map; against float64"""
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(19 + mapped_terms)
+    n_v, Mrows, Kc, N, T = 12000, 9000, 128, 160, 3
+    rowmap = np.sort(rng.choice(n_v, Mrows, replace=False)).astype(np.int32)
+    rng.shuffle(rowmap[: Mrows // 2])                                          # not monotone
+    terms = [rng.standard_normal((n_v if (mapped_terms >> t) & 1 else Mrows, Kc)).astype(np.float32) for t in range(T)]
+    W = (rng.standard_normal((T, Kc, N)) / np.sqrt(T * Kc)).astype(np.float32)
+    bias = rng.standard_normal((n_v, N)).astype(np.float32)
+    out = torch.full((1, n_v, N), 7.0, device="cuda")
+    F.project_mapped([_dev(t) for t in terms], [0] * T, _dev(W.reshape(T * Kc, N)), _dev(bias), 2, n_v, _dev(rowmap), mapped_terms, 1, out)
+    ref = np.full((n_v, N), 7.0)
+    acc = sum((t[rowmap] if (mapped_terms >> k) & 1 else t).astype(np.float64) @ W[k].astype(np.float64) for k, t in enumerate(terms))
+    ref[rowmap] = acc + bias[rowmap]
+    assert rel_err(out[0].cpu().numpy(), ref) <= TOL
