@@ -581,8 +581,8 @@ def test_hot_kernels_do_not_spill():
     """project_x3_stream_kernel runs 1024-thread workgroups at exactly 128 VGPRs with up to 150 KB of dynamic LDS; a compiler update
     that makes it (or the hop kernel) spill would show up only as a slower bench.  The gfx950 code object's own metadata says what the BUILT
     library uses (tools/kernel_resources.py): the hop kernel of the headline and the wide bf16x3 projection must be spill-free, the streaming
-    projection may keep the four loop-invariant VGPRs it parks in scratch before its tile loop today (<4, 2>: 20 bytes, stored and loaded
-    once per wave, outside the loop) and nothing more."""
+    projection may keep the ONE loop-invariant 64-bit address it parks in scratch across its weight-staging prologue today (<4, 2>: 2 VGPRs,
+    12 bytes, stored and loaded once per wave, outside the tile loop; round 5's binary parked four) and nothing more."""
     import shutil
     from tgcn_amd import _lib
     from tools import kernel_resources as kr
@@ -599,5 +599,5 @@ def test_hot_kernels_do_not_spill():
         assert r["vgpr_spill_count"] == 0 and r["sgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
     for name, r in stream.items():
         assert r["vgpr_count"] <= 128, (name, r)                              # 1024 threads per workgroup: 4 waves per SIMD
-        assert r["vgpr_spill_count"] <= 4 and r["private_segment_fixed_size"] <= 20 and r["uses_dynamic_stack"] in ("false", 0), (name, r)
+        assert r["vgpr_spill_count"] <= 2 and r["private_segment_fixed_size"] <= 12 and r["uses_dynamic_stack"] in ("false", 0), (name, r)
     assert shutil.which("true")

@@ -1133,7 +1133,8 @@ __global__ __launch_bounds__(1024) void project_x3_stream_kernel(const ProjParam
   extern __shared__ __align__(16) unsigned char stream_smem[];
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
   bf16x8* Wf = reinterpret_cast<bf16x8*>(stream_smem);        // [term][kt][nt][plane][lane]: 16 bytes per lane
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the tile counters below live in scalar registers (the <4, 2> form is at its 128-VGPR cap)
   const int r16 = lane & 15, g = lane >> 4;
   {
     const int nfrag = p.nterms * KTILES * NT * 64;
@@ -1163,13 +1164,16 @@ __global__ __launch_bounds__(1024) void project_x3_stream_kernel(const ProjParam
   // loaded a whole tile ahead so that no unit's loads wait for it
   // (row numbers as 32-bit values: the host refuses M or n_vertices beyond int32 for this kernel; four 64-bit row registers cost the <4, 2>
   //  instantiation its last spill-free registers)
+  // (round 6: the tile number is wave-uniform and lives in scalar registers, and a lane's clamped row of a tile is RECOMPUTED from it where
+  //  it is needed -- two vector instructions -- instead of being carried across the tile loop for this and the next tile: the <4, 2>
+  //  instantiation kept four loop-invariant registers in scratch before its loop)
   int64_t tile = (int64_t)blockIdx.x * 16 + wave;
-  int32_t mrow = 0, rrow = 0, rrow_next = 0;
-  bool row_ok = false;
-  auto tile_rows = [&](int64_t t, int32_t& m_c) { const int64_t m = t * 16 + r16; m_c = (int32_t)(m < p.M ? m : p.M - 1); return m < p.M; };
+  int32_t rrow = 0, rrow_next = 0;
+  auto row_of = [&](int64_t t) -> int32_t { const int64_t m = t * 16 + r16; return (int32_t)(m < p.M ? m : p.M - 1); };
+  auto ok_of = [&](int64_t t) -> bool { return t * 16 + r16 < p.M; };
   auto fetch_map = [&](int64_t t) -> int32_t {
     if (t >= ntiles) return 0;
-    int32_t m_c; (void)tile_rows(t, m_c);
+    const int32_t m_c = row_of(t);
     return p.rowmap ? p.rowmap[m_c] : m_c;
   };
   float xa[KTILES * 8], xb[KTILES * 8];
@@ -1257,32 +1261,30 @@ __global__ __launch_bounds__(1024) void project_x3_stream_kernel(const ProjParam
   };
 
   if (tile < ntiles) {
-    row_ok = tile_rows(tile, mrow);
     rrow = fetch_map(tile);
     rrow_next = fetch_map(tile + nwaves);
-    load_unit(0, mrow, rrow, xa);
+    load_unit(0, row_of(tile), rrow, xa);
   }
   while (tile < ntiles) {
-    const int64_t orow = map_out ? rrow : mrow;
+    const int64_t orow = map_out ? rrow : row_of(tile);
+    const bool row_ok = ok_of(tile);
     load_bias(orow);
     const int64_t tile_n = tile + nwaves;
-    int32_t mrow_n = 0;
-    const bool ok_n = tile_n < ntiles ? tile_rows(tile_n, mrow_n) : false;
     // units of this tile two at a time (statically named register buffers); the unit after the tile's last one is unit 0 of the next tile
     for (int u = 0; u < units; u += 2) {
-      if (u + 1 < units) load_unit(u + 1, mrow, rrow, xb);
-      else if (tile_n < ntiles) load_unit(0, mrow_n, rrow_next, xb);
+      if (u + 1 < units) load_unit(u + 1, row_of(tile), rrow, xb);
+      else if (tile_n < ntiles) load_unit(0, row_of(tile_n), rrow_next, xb);
       compute_unit(u, xa, orow, row_ok);
       if (u + 1 >= units) {                                      // odd unit count: the prefetched unit belongs to the next tile -> move it to xa
 #pragma unroll
         for (int i = 0; i < KTILES * 8; ++i) xa[i] = xb[i];
         break;
       }
-      if (u + 2 < units) load_unit(u + 2, mrow, rrow, xa);
-      else if (tile_n < ntiles) load_unit(0, mrow_n, rrow_next, xa);
+      if (u + 2 < units) load_unit(u + 2, row_of(tile), rrow, xa);
+      else if (tile_n < ntiles) load_unit(0, row_of(tile_n), rrow_next, xa);
       compute_unit(u + 1, xb, orow, row_ok);
     }
-    tile = tile_n; mrow = mrow_n; row_ok = ok_n; rrow = rrow_next;
+    tile = tile_n; rrow = rrow_next;
     rrow_next = fetch_map(tile + nwaves);
   }
 }
