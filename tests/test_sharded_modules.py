@@ -421,3 +421,66 @@ def test_sharded_edge_list_modules(world, timed, weighted):
         assert nshards == 1
         covered[lo:hi] += 1
     assert np.all(covered == 1)
+
+
+# ------------------------------------------------------------------------------------------------ random sweep
+def _fuzz_worker(rank, world, port, ret, seed, cases):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tgcn_amd.dist import VertexShardedCheb
+        rng = np.random.default_rng(seed)                    # the same stream on every rank: the same cases
+        out = []
+        for case in range(cases):
+            n = int(rng.integers(40, 260))
+            q = int(rng.integers(1, 5))
+            K = int(rng.choice([1, 2, 3, 5, 7]))
+            C = int(rng.choice([1, 3, 4, 7, 16, 33]))
+            N = int(rng.choice([1, 2, 5, 8, 17]))
+            mode = int(rng.integers(0, 2))
+            bias_kind = int(rng.integers(0, 3))
+            exchange = str(rng.choice(["halo", "allgather", "auto"]))
+            banded = bool(rng.integers(0, 2))
+            depth = int(rng.integers(1, 4))
+            row, col, val = _graph(n, int(rng.integers(0, 10 ** 6)), banded)
+            if rng.integers(0, 2):                               # a block of vertices without entries (padded coarsened graphs, R-MAT)
+                dead = rng.choice(n, n // 5, replace=False)
+                keep = ~np.isin(row, dead)
+                row, col, val = row[keep], col[keep], val[keep]
+            x = rng.standard_normal((q, n, C)).astype(np.float32)
+            W = (rng.standard_normal((K, C, N)) / 3).astype(np.float32)
+            bias = None if bias_kind == 0 else (rng.standard_normal(N).astype(np.float32) if bias_kind == 1 else rng.standard_normal((n, N)).astype(np.float32))
+            g = rng.standard_normal((q, n, N)).astype(np.float32)
+            sh = VertexShardedCheb(n, torch.as_tensor(row), torch.as_tensor(col), torch.as_tensor(val), device="cpu", exchange=exchange, ops=CpuOps())
+            xl = torch.from_numpy(np.ascontiguousarray(x[:, sh.lo:sh.hi]))
+            bl = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias if bias_kind == 1 else bias[sh.lo:sh.hi]))
+            Wt = torch.from_numpy(W)
+            o1 = sh.layer(xl, Wt, bl, bias_kind, mode, depth=depth)
+            same = bool(torch.equal(o1, sh.layer(xl, Wt, bl, bias_kind, mode, overlap=False)))
+            o2 = sh.layer(xl, Wt, bl, bias_kind, mode, project_first=not sh.use_project_first(C, N, K))
+            gx, gW, gb = sh.layer_backward(xl, Wt, torch.from_numpy(np.ascontiguousarray(g[:, sh.lo:sh.hi])), bias_kind, mode)
+            L = O.coo_to_csr(row, col, val, n)
+            ref = _ref_forward(L, x, W, bias, mode)
+            rx, rW = O.layer_backward(L, x, W, g, "power" if mode == 0 else "chebyshev")
+            s_o, s_x, s_w = max(np.abs(ref).max(), 1e-30), max(np.abs(rx).max(), 1e-30), max(np.abs(rW).max(), 1e-30)
+            errs = [float(np.abs(o1.numpy() - ref[:, sh.lo:sh.hi]).max() / s_o), float(np.abs(o2.numpy() - ref[:, sh.lo:sh.hi]).max() / s_o),
+                    float(np.abs(gx.numpy() - rx[:, sh.lo:sh.hi]).max() / s_x), float(np.abs(gW.numpy() - rW).max() / s_w)]
+            if bias_kind:
+                rb = g.astype(np.float64).sum((0, 1)) if bias_kind == 1 else g.astype(np.float64).sum(0)[sh.lo:sh.hi]
+                errs.append(float(np.abs(gb.numpy() - rb).max() / max(np.abs(rb).max(), 1e-30)))
+            out.append((dict(n=n, q=q, K=K, C=C, N=N, mode=mode, bias_kind=bias_kind, exchange=sh.exchange, banded=banded, depth=depth), same, errs))
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,seed", [(2, 101), (3, 202)])
+def test_random_sweep_of_the_sharded_layer(world, seed):
+    """20 random shapes per world size: K = 1 ... 7, widths 1 ... 33 in and 1 ... 17 out (both evaluation orders each), both recurrences, three bias
+    kinds, three exchange settings, pipeline depth 1 ... 3, graphs with and without a small cut and with vertices that have no entries -- forward in
+    both orders, overlapped == plain bit for bit, all gradients against the oracle"""
+    res = _spawn(_fuzz_worker, world, seed, 20)
+    for per_rank in res:
+        for cfg, same, errs in per_rank:
+            assert same, cfg
+            assert max(errs[:2]) <= TOL and max(errs[2:]) <= 5e-5, (cfg, errs)
