@@ -285,8 +285,10 @@ class VertexShardedCheb:
         inv = torch.empty_like(order)
         inv[order] = torch.arange(self.owned, device=self.device)
         self.local_inv = inv
-        self.perm32 = order.to(torch.int32) if exchange == "halo" else None      # row maps of the projections (None: identity)
-        self.inv32 = inv.to(torch.int32) if exchange == "halo" else None
+        # (a shard whose rows are all interior or all boundary -- world size 1, a rank inside one connected block -- keeps the caller's order)
+        self._permuted = exchange == "halo" and 0 < self.n_int < self.owned
+        self.perm32 = order.to(torch.int32) if self._permuted else None           # row maps of the projections (None: identity)
+        self.inv32 = inv.to(torch.int32) if self._permuted else None
         r2 = inv[r]                                                                  # row in the [interior | boundary] order
         if exchange == "halo":
             c2 = torch.where(c_local < self.owned, inv[c_local.clamp(max=max(self.owned - 1, 0))], c_local)    # owned columns move with their rows
@@ -339,10 +341,10 @@ class VertexShardedCheb:
 
     def _to_shard_order(self, src, out):
         """owned rows in the caller's order -> the shard's [interior | boundary] order"""
-        return self._rows(src, self.local_perm, out) if self.exchange == "halo" else out.copy_(src)
+        return self._rows(src, self.local_perm, out) if self._permuted else out.copy_(src)
 
     def _to_caller_order(self, src, out):
-        return self._rows(src, self.local_inv, out) if self.exchange == "halo" else out.copy_(src)
+        return self._rows(src, self.local_inv, out) if self._permuted else out.copy_(src)
 
     # ------------------------------------------------------------------ diagnostics
     def describe(self, width=None):
@@ -519,7 +521,7 @@ class VertexShardedCheb:
         bk = bias_kind if bias_local is not None else 0
         if pf:
             bias_s = bias_local
-            if bk == 2 and self.exchange == "halo":           # the projection adds the bias at its OUTPUT row, which is in shard order
+            if bk == 2 and self._permuted:                    # the projection adds the bias at its OUTPUT row, which is in shard order
                 bias_s = self._rows(bias_local.reshape(owned, N), self.local_perm)
             Z = ops.project_first(x_local.contiguous(), ops.weight_layout(W, 0), bias_s, bk, K, N, rowmap=self.inv32)      # (q, owned, K*N), shard order
             self._mark(marks, "projection_ms")
