@@ -18,7 +18,11 @@ algorithmic bytes per launch / mean launch duration from hipEvents recorded arou
 steps) and `cpu_baseline` (oracle/cheb_ref.c, OpenMP, timed on this box's host cores on a bounded sample).
 `roofline.physical_*`: the same for the bytes a launch physically has to move once (entries, row pointers, and only the rows that exist in
 the hop tensors -- compaction is fewer rows processed, not more bandwidth); `roofline.mean_launch_ms_by_hop`: by hop position.
-N > 1: the vertex-sharded / hybrid extras (`other_shardings`) size themselves to --extras-budget and never decide the exit code.
+N > 1: the vertex-sharded / hybrid extras (`other_shardings`) size themselves to --extras-budget and never decide the exit code; they run through
+the sharded MODULES (tgcn_amd.dist.ShardedTGCNCheb / ShardedTGCNCheb_H).  `--shard vertex` without a launcher forms a one-rank group itself.
+The default run (cfg5, one GPU) also carries `other_workloads` -- the R-MAT with degree-sorted labels, cfg2 (f = 1 and 64), cfg3, cfg4, each with ms
+per forward, its dominant kernel's roofline and the GPU-vs-CPU errors, measured after the headline with its memory freed (--no-others skips them) --
+and times the CPU baseline on as many time steps as --cpu-budget seconds allow (`cpu_baseline.samples_timed`, `scaled_from`, `host`).
 """
 import argparse
 import json
