@@ -433,3 +433,54 @@ def test_random_sweep_of_the_sharded_layer_hip_two_ranks_one_gpu(gpu_device):
         for cfg, same, errs in ret[r]:
             assert same, cfg
             assert max(errs[:2]) <= 1e-5 and max(errs[2:]) <= 5e-5, (cfg, errs)
+
+
+def _nccl_module_worker(rank, world, port, ret):
+    """the sharded MODULE between real peers: rank r on cuda:r, RCCL transport (runs only where the box has the GPUs)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from tgcn_amd import dist as tdist
+        from tools import synth
+        n, row, col, val = synth.sheet_mesh(100, device="cpu")            # the CPU generator: the same graph on every rank whatever its device
+        H, g_ch, K, q = 240, 32, 5, 2
+        torch.manual_seed(1)
+        layer = tdist.ShardedTGCNCheb_H(tdist.CooGraph(n, row, col, val), 1, g_ch, K, H).to(dev)
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal((q, n, H)).astype(np.float32)
+        gout = rng.standard_normal((q, n, g_ch)).astype(np.float32)
+        lo, hi = layer.owned_rows(dev)
+        xl = torch.as_tensor(np.ascontiguousarray(x[:, lo:hi])).to(dev).requires_grad_(True)
+        out = layer(xl)
+        layer.overlap = False
+        with torch.no_grad():
+            plain = layer(xl)
+        layer.overlap = True
+        out.backward(torch.as_tensor(np.ascontiguousarray(gout[:, lo:hi])).to(dev))
+        torch.cuda.synchronize()
+        L = O.coo_to_csr(row.numpy(), col.numpy(), val.numpy(), n)
+        W, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+        ref = O.tgcn_cheb_h_forward(L, x, W, b)
+        rx, rW = O.layer_backward(L, x[..., None], W, gout, "power")
+        rel = lambda a, b_, full: float(np.abs(a - b_).max() / np.abs(full).max())          # noqa: E731
+        ret[rank] = (rel(out.detach().cpu().numpy(), ref[:, lo:hi], ref), bool(torch.equal(out.detach(), plain)),
+                     rel(xl.grad.cpu().numpy(), rx.reshape(x.shape)[:, lo:hi], rx), rel(layer.weight.grad.cpu().numpy(), rW, rW),
+                     rel(layer.bias.grad.cpu().numpy(), gout.astype(np.float64).sum(0)[None], gout.astype(np.float64).sum(0)), layer.shard(dev).describe()["row_floats"], hi - lo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL between real peers)")
+def test_sharded_module_two_ranks_two_gpus_rccl():
+    """ShardedTGCNCheb_H (project-first: 32-float halo rows) forward + backward over RCCL between two GPUs: never run on this pool (one GPU per lease),
+    kept ready for the first box that has a peer -- the same assertions as the two-ranks-one-GPU gloo tests above"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_module_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world and sum(ret[r][6] for r in range(world)) == 10000
+    for r in range(world):
+        e_out, same, e_x, e_W, e_b, width, _ = ret[r]
+        assert e_out <= 1e-5 and same and max(e_x, e_W, e_b) <= 2e-5 and width == 32, ret[r]
