@@ -484,3 +484,55 @@ def test_sharded_module_two_ranks_two_gpus_rccl():
     for r in range(world):
         e_out, same, e_x, e_W, e_b, width, _ = ret[r]
         assert e_out <= 1e-5 and same and max(e_x, e_W, e_b) <= 2e-5 and width == 32, ret[r]
+
+
+def _cfg5_worker(rank, world, port, ret):
+    """BASELINE.json configs[4] at FULL size, vertex-sharded over two ranks on one GPU (gloo transport, HIP kernels): R-MAT 10 M / 160 M,
+    ShardedTGCNCheb(L, 64, 64, 5), ONE time step, against oracle/cheb_ref.c on the whole graph"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="64")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import c_port
+        from tgcn_amd import dist as tdist
+        from tools import synth
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        n, nnz = 10_000_000, 160_000_000
+        _, row, col, val = synth.rmat(n, nnz, seed=12345, labeling="random", device=dev)
+        torch.manual_seed(1)
+        layer = tdist.ShardedTGCNCheb(tdist.CooGraph(n, row, col, val), 64, 64, 5, exchange="auto").to(dev)
+        lo, hi = layer.owned_rows(dev)
+        sh = layer.shard(dev)
+        layer.L = tdist.CooGraph(n, row[:0], col[:0], val[:0])
+        gen = torch.Generator(device="cuda").manual_seed(0)
+        x = torch.randn((1, n, 64), device=dev, generator=gen)
+        xl = x[:, lo:hi].contiguous()
+        with torch.no_grad():
+            out = layer(xl)
+        torch.cuda.synchronize()
+        d = sh.describe()
+        # the whole-graph oracle on this rank's host cores (both ranks compute it: ~2 x 12 s sharing the box)
+        order = torch.argsort(row * n + col)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0)
+        rp, ci, va = rowptr.to(torch.int32).cpu().numpy(), col[order].to(torch.int32).cpu().numpy(), val[order].cpu().numpy()
+        del row, col, val, order
+        ref = c_port.forward(0, rp, ci, va, x.cpu().numpy(), layer.weight.detach().cpu().numpy(), layer.bias.detach().reshape(-1).cpu().numpy(), 2)
+        err = float(np.abs(out.cpu().numpy() - ref[:, lo:hi]).max() / np.abs(ref).max())
+        ret[rank] = (err, sh.exchange, d["row_floats"], d["halo_rows"], d["bytes_in_per_hop_and_time_step"], hi - lo, sh.n_int)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg5_full_size_vertex_sharded_world2_one_gpu(gpu_device):
+    """the headline graph through the vertex-sharded module at FULL size: 5 M-row shards, ~1.9 M halo rows of 64 floats per hop (the halo form: 38 % of
+    the remote vertices), interior + boundary operands with long rows and fix-ups, 64-bit offsets -- <= 1e-5 against the C restatement"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cfg5_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world and sum(ret[r][5] for r in range(world)) == 10_000_000
+    for r in range(world):
+        err, used, width, halo, nbytes, owned, n_int = ret[r]
+        assert err <= 1e-5, ret[r]
+        assert used == "halo" and width == 64 and 1_500_000 < halo < 2_500_000 and nbytes == halo * 256 and 0 < n_int < owned, ret[r]
