@@ -392,37 +392,89 @@ class VertexShardedCheb:
         self.stats = {k: round(v, 3) for k, v in tot.items()}
 
     # ------------------------------------------------------------------ the exchange of one hop
+    # ------------------------------------------------------------------ host transports (gloo): staged through pinned host memory
+    # RCCL collectives are ordered on the device's streams: the exchange is enqueued behind the kernels that produce its data, wait() is a
+    # stream dependency, receives land IN PLACE.  A host transport must never be handed a device pointer: torch's gloo send / recv take
+    # `tensor.data_ptr()` as HOST memory -- on this platform the CPU can indeed address device memory, so nothing fails, but the bytes move
+    # with no ordering against the stream (a pack kernel still queued, a hop still reading the buffer) and behind the GPU's L2 (a boundary
+    # hop launched back to back with the interior one keeps lines of the receive region it had cached).  Seen as: cfg4 on two gloo ranks off
+    # by 2.5 % and different run to run (fixed first by draining the stream before posting), then the full-size R-MAT failing one run in
+    # five.  So on anything but nccl the messages are staged: device -> pinned host (stream-ordered copy, then a host wait), gloo on the HOST
+    # buffers, pinned host -> device on the compute stream when the work is waited for.  Rehearsal transports only; RCCL never comes here.
+    def _host_staged(self):
+        return self.device.type == "cuda" and self.comm_device.type != "cuda"
+
+    def _hbuf(self, name, shape):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._bufs[name] = torch.zeros(shape, dtype=torch.float32).pin_memory()
+        return t
+
+    class _StagedWork:
+        """a posted host-side operation + the copies that bring what it received back to the device when it is waited for"""
+
+        def __init__(self, works, copies):
+            self.works, self.copies = works, copies
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+            for dst, src in self.copies:
+                dst.copy_(src, non_blocking=True)         # pinned host -> device, ordered on the compute stream like the kernels that read it
+            return True
+
     def _post(self, slot, k, src_ext, mine=None, async_op=True):
         """Start fetching the remote rows of a hop tensor; returns the work handles.
         halo: `src_ext` (1, n_ext, w) with its owned part valid -- messages are packed by the pack kernel into per-peer send buffers and
         received IN PLACE into its own halo region.  all-gather: `mine` (n_max, w) block of this rank -> `src_ext` (1, world * n_max, w)."""
         w = src_ext.shape[2]
-        self._fence()
+        staged = self._host_staged()
         if self.exchange != "halo":
+            if staged:
+                mine_h = self._hbuf(("mine_h", w, slot), (self.n_max, w))
+                ext_h = self._hbuf(("gath_h", w, slot), (self.world * self.n_max, w))
+                mine_h.copy_(mine)                                                   # (blocking: the producing kernels have finished)
+                h = dist.all_gather_into_tensor(ext_h, mine_h, group=self.group, async_op=async_op)
+                work = self._StagedWork([h] if h is not None else [], [(src_ext.view(self.world * self.n_max, w), ext_h)])
+                if not async_op:
+                    work.wait()
+                    return []
+                return [work]
             h = dist.all_gather_into_tensor(src_ext.view(self.world * self.n_max, w), mine, group=self.group, async_op=async_op)
             return [h] if h is not None else []
-        ops = []
+        ops, copies = [], []
         off = self.owned
         for p in range(self.world):
             cnt = self.recv_counts[p]
             if p != self.rank and cnt:
-                ops.append(dist.P2POp(dist.irecv, src_ext[0, off: off + cnt], self.peer[p], group=self.group))
+                dst = src_ext[0, off: off + cnt]
+                if staged:
+                    rb = self._hbuf(("recv_h", w, slot, k & 1, p), (cnt, w))
+                    copies.append((dst, rb))
+                    dst = rb
+                ops.append(dist.P2POp(dist.irecv, dst, self.peer[p], group=self.group))
             off += cnt
             idx = self.send_idx_l[p]
             if p != self.rank and idx.numel():
                 sb = self._buf(("send", w, slot, k & 1, p), (idx.numel(), w))
                 self.ops.pack(src_ext[0], idx, sb)
+                if staged:
+                    sh_ = self._hbuf(("send_h", w, slot, k & 1, p), (idx.numel(), w))
+                    sh_.copy_(sb)                                                    # stream-ordered behind the pack kernel, host waits for it
+                    sb = sh_
                 ops.append(dist.P2POp(dist.isend, sb, self.peer[p], group=self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return [self._StagedWork(works, copies)] if staged and works else works
 
-    def _fence(self):
-        """RCCL collectives are ordered on the device's streams (the exchange is enqueued behind the kernels that produce its data, wait() is a
-        stream dependency).  A HOST transport is not: gloo reads and writes device memory from the CPU the moment a send / receive is posted --
-        while the pack kernel that fills the send buffer, or a hop that still reads the buffer a receive lands in, may only be queued
-        (measured on cfg4 with two gloo ranks on one GPU: results off by 2.5 % and different from run to run without this).  So before posting on
-        anything but nccl the device drains.  Rehearsal transports only; the RCCL path never takes it."""
-        if self.device.type == "cuda" and self.comm_device.type != "cuda":
-            torch.cuda.current_stream(self.device).synchronize()
+    def _all_reduce(self, t, group):
+        """sum over the group; staged through the host for host transports"""
+        if self._host_staged():
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
 
     def _hop(self, op, src, z, alpha, beta, z2, gamma, out):
         if z is None and z2 is not None:
@@ -594,16 +646,12 @@ class VertexShardedCheb:
             if needs[0]:
                 gx = T.forward(g, ops.weight_layout(Wt, 1), None, 0, mode, overlap=overlap, depth=depth)
         if needs[1]:
-            gW = gW.contiguous()
-            self._fence()
-            dist.all_reduce(gW, op=dist.ReduceOp.SUM, group=grad_group)
+            gW = self._all_reduce(gW.contiguous(), grad_group)
             if mode == 0:
                 gW = ops.fold(gW, transpose=True)
         if needs[2] and bias_kind:
             if bias_kind == 1:
-                gb = g.sum(dim=(0, 1))
-                self._fence()
-                dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=grad_group)
+                gb = self._all_reduce(g.sum(dim=(0, 1)), grad_group)
             else:
                 gb = g.sum(dim=0)
         return gx, gW, gb
@@ -645,7 +693,12 @@ class _OwnedRowsFn(torch.autograd.Function):
         out = torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
         out[ctx.lo: ctx.hi] = g
         if ctx.sync:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=ctx.group)
+            if out.is_cuda and dist.get_backend(ctx.group) != "nccl":       # host transport: through host memory (VertexShardedCheb._post)
+                h = out.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=ctx.group)
+                out.copy_(h)
+            else:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=ctx.group)
         return out, None, None, None, None
 
 
