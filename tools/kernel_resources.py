@@ -23,7 +23,9 @@ def code_object(so_path, arch="gfx950"):
     """bytes of the device ELF for `arch` inside the shared library"""
     with tempfile.TemporaryDirectory() as d:
         fat = os.path.join(d, "fat.bin")
-        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path], check=True)
+        # (an explicit output file: objcopy with ONE file argument rewrites its input in place -- round 6 found the product library 600 KB larger and
+        #  re-stamped after every CPU test run)
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path, os.path.join(d, "copy.so")], check=True)
         b = open(fat, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     assert b.startswith(magic), "not a clang offload bundle"
