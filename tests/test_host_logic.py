@@ -588,7 +588,10 @@ def test_hot_kernels_do_not_spill():
     from tools import kernel_resources as kr
     if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(os.path.join(kr.LLVM, "llvm-readelf")):
         pytest.skip("needs the built library and llvm-readelf")
+    import hashlib
+    before = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
     res = kr.kernel_resources(_lib.LIB_PATH)
+    assert hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest() == before      # reading the metadata must not rewrite the product library
     assert len(res) > 200
     by = lambda frag: {k: v for k, v in res.items() if frag in k}          # noqa: E731 -- mangled names
     hop = by("10hop_kernelILi16ELi4ELi8ELi1E")
