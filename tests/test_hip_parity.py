@@ -1084,3 +1084,30 @@ def test_wide_projection_through_a_row_map(mapped_terms, gpu_device):
     acc = sum((t[rowmap] if (mapped_terms >> k) & 1 else t).astype(np.float64) @ W[k].astype(np.float64) for k, t in enumerate(terms))
     ref[rowmap] = acc + bias[rowmap]
     assert rel_err(out[0].cpu().numpy(), ref) <= TOL
+
+
+@pytest.mark.parametrize("q,rows,C,K,N", [(1, 3000, 64, 5, 8), (3, 9000, 64, 5, 8), (2, 9000, 1200, 5, 32), (2, 5000, 12, 4, 4), (4, 700, 33, 3, 5),
+                                          (1, 40000, 64, 2, 32), (2, 20000, 32, 5, 12)])
+@pytest.mark.parametrize("mapped", [False, True])
+def test_project_first_entry_vs_numpy(q, rows, C, K, N, mapped, gpu_device):
+    """tgcn_cheb_project_first_f32 (ABI v7: the first step of the project-first form on its own) on every projection kernel its shapes reach --
+    W-resident, tiled bf16x3 with the samples inside the launch, the wide bf16x3 kernel, the vector-ALU kernel, unaligned scalar forms -- with
+    and without an OUTPUT row map, three bias kinds (the bias rides on the first N of the K*N columns, read at the output row); against float64"""
+    from tgcn_amd import functional as F
+    rng = np.random.default_rng(q * rows + C)
+    x = rng.standard_normal((q, rows, C)).astype(np.float32)
+    Wcat = (rng.standard_normal((C, K * N)) / np.sqrt(C)).astype(np.float32)
+    rowmap = rng.permutation(rows).astype(np.int32) if mapped else None
+    for kind, bias in ((0, None), (1, rng.standard_normal(N).astype(np.float32)), (2, rng.standard_normal((rows, N)).astype(np.float32))):
+        Z = F.project_first(_dev(x), _dev(Wcat), None if bias is None else _dev(bias), kind, K, N, rowmap=None if rowmap is None else _dev(rowmap))
+        ref = x.astype(np.float64) @ Wcat.astype(np.float64)
+        if mapped:
+            out = np.empty_like(ref)
+            out[:, rowmap] = ref
+            ref = out
+        if kind == 1:
+            ref[:, :, :N] += bias
+        elif kind == 2:
+            ref[:, :, :N] += bias[None]
+        assert tuple(Z.shape) == (q, rows, K * N)
+        assert rel_err(Z.cpu().numpy(), ref) <= TOL, (kind, mapped)
